@@ -1,0 +1,195 @@
+/*
+ * ml2048_hip.h - C ABI of libml2048_hip.so: the MI355X (gfx950) vectorized 2048 environment.
+ *
+ * The reference (tsangwpx/ml2048 @ 2024_10_08) has no FFI: its hot path is a Python class
+ * (`VecGame`, src/ml2048/game_numba.py:522-698) whose per-board work numba JIT-compiles
+ * (`_vec_step` :701-738 and the helpers it inlines).  This header is the boundary a drop-in
+ * replacement of that path binds instead of numba: every entry point below names the reference
+ * lines it replaces.  INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no C++ / torch types.
+ *  - Every buffer is CALLER-OWNED DEVICE memory (e.g. torch.empty(..., device="cuda").data_ptr());
+ *    the library allocates nothing and keeps no state between calls (re-entrant; one host
+ *    thread per GPU is fine).
+ *  - `stream` is a hipStream_t (NULL = the null stream).  All work is enqueued asynchronously;
+ *    no entry point synchronizes.  All launches are hipGraph-capturable.
+ *  - Return 0 on success; < 0 library error (ML2048_E_*), > 0 a hipError_t.  Text of the last
+ *    error of the calling thread: ml2048_last_error().
+ *  - Board cells are tile EXPONENTS (0 empty, k = tile 2^k), one uint8 each, cell 4*row+col
+ *    (game_numba.py:13-20).  Actions: 0 left, 1 right, 2 up, 3 down (src/ml2048/game.py:14-17).
+ */
+#ifndef ML2048_HIP_H
+#define ML2048_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ML2048_ABI_VERSION 1
+#define ML2048_RAND_SIZE 1024 /* VecGame._RAND_SIZE, game_numba.py:533 */
+
+enum { ML2048_E_INVALID = -1, ML2048_E_ALIGN = -2, ML2048_E_UNSUPPORTED = -3 };
+enum { ML2048_REWARD_NORMAL = 0, ML2048_REWARD_IMPROVED = 1, ML2048_REWARD_RANK = 2, ML2048_REWARD_MAXCELL = 3 };
+enum { ML2048_ACT_U8 = 0, ML2048_ACT_I32 = 1, ML2048_ACT_I64 = 2 };
+
+/*
+ * Device-resident game state, structure-of-arrays.  Field for field the reference's 64-byte
+ * record `VecGame._DATA_SPEC` (game_numba.py:537-551) plus its two persistent copies
+ * `_prev_state` / `_prev_valid_actions` (:574-575), split per field so that one wavefront's
+ * 64 boards are one contiguous, fully coalesced segment of every array.
+ * `board`, `merged`, `prev_board` must be 16-byte aligned; the 4-byte fields 4-byte aligned.
+ */
+typedef struct ml2048_state {
+    uint8_t *board;      /* [M][16]  data["board"]          */
+    uint8_t *merged;     /* [M][16]  data["merged"]         */
+    uint8_t *valid;      /* [M][4]   data["valid_actions"]  (L,R,U,D as 0/1) */
+    int32_t *step;       /* [M]      data["step"]           */
+    float *score;        /* [M]      data["score"]          */
+    float *reward;       /* [M]      data["reward"]         */
+    uint8_t *terminated; /* [M]      data["terminated"]     */
+    uint8_t *invalid;    /* [M]      data["invalid"]        */
+    int32_t *id;         /* [M]      data["id"]             */
+    uint8_t *prev_board; /* [M][16]  VecGame._prev_state         */
+    uint8_t *prev_valid; /* [M][4]   VecGame._prev_valid_actions */
+} ml2048_state;
+
+int ml2048_abi_version(void);
+const char *ml2048_last_error(void);
+/* number of int32 words of device scratch ml2048_prepare* needs for M boards */
+int64_t ml2048_scratch_ints(int64_t M);
+
+/* VecGame.reset's record part (game_numba.py:613-617): zero every field, terminated = 1. */
+int ml2048_reset(void *stream, int64_t M, const ml2048_state *st);
+
+/*
+ * VecGame.prepare's reset loop (game_numba.py:629-658): every terminated board is zeroed, gets
+ * id = *game_count + (its rank among the terminated boards, ascending slot order), two tiles from
+ * table row (row_base + idx_base + idx) mod 1024 (`_spawn2(..., 2)`, :648-655) and its
+ * valid-action mask (:656).  row_base = rand_step + rand_offset drawn by the host (:622-626).
+ *   game_count    device int32, advanced by the number of resets (VecGame._game_count)
+ *   n_reset       device int32 out: number of boards reset
+ *   reset_indices device int64[M] out or NULL: the ascending slots (the tuple prepare() returns)
+ *   scratch       device int32[ml2048_scratch_ints(M)]
+ * randperm: device uint8[1024][16]; randfloat: device float[1024] (VecGame._randperm/_randfloat).
+ */
+int ml2048_prepare(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st,
+                   const uint8_t *randperm, const float *randfloat, double two_prob,
+                   int64_t row_base, int32_t *game_count, int32_t *n_reset,
+                   int64_t *reset_indices, int32_t *scratch);
+
+/*
+ * VecGame.step's device part: the two copies (game_numba.py:672-673) and `_vec_step`
+ * (:701-738) - slide/merge (`_step_kernel` :125-134, `_push_row` :48-90), reward_fn (:408-504,
+ * selected by reward_kind), score, one-tile spawn from table row (row_base + idx_base + idx) mod
+ * 1024 (`_spawn2`, :172-212), valid mask (`_compute_valid_actions` :259-289), terminated/invalid.
+ * An action that is not currently valid only sets invalid = 1 (:737-738).  Actions outside 0..3
+ * are treated as invalid.  row_base = rand_step + rand_offset drawn by the host (:670, :681).
+ */
+int ml2048_step(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st,
+                const void *actions, int action_dtype, int reward_kind, double two_prob,
+                int64_t row_base, const uint8_t *randperm, const float *randfloat);
+
+/*
+ * Fast mode (no reference counterpart; NOT bit-exact with the numba path, statistically the same
+ * game): the spawn uses rocRAND's Philox4x32-10 device generator keyed (seed; subsequence =
+ * idx_base + idx; offset = 4 * counter) instead of the host PCG64 tables.  Cell = k-th empty cell,
+ * k = (word0 * n_empty) >> 32; tile "2" iff word1 < ceil(two_prob * 2^32).  prepare uses words
+ * 0..3 for its two tiles.  Bit-exact against oracle/ml2048_oracle.c orc_*_fast.
+ */
+int ml2048_prepare_fast(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st,
+                        double two_prob, uint64_t seed, uint64_t counter, int32_t *game_count,
+                        int32_t *n_reset, int64_t *reset_indices, int32_t *scratch);
+int ml2048_step_fast(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st,
+                     const void *actions, int action_dtype, int reward_kind, double two_prob,
+                     uint64_t seed, uint64_t counter);
+
+/*
+ * Uniform action sampling (RandomPolicy.sample_actions, src/ml2048/policy/random.py:17-27 with
+ * categorical_sample, src/ml2048/stats.py:32-47: uniform over the valid actions, log-prob
+ * -log(#valid)).  torch.multinomial's stream is not reproducible across devices, so the stream is
+ * defined here: word = Philox4x32-10(key = seed, counter = {counter, idx_base + idx})[0];
+ * masked: action = the ((word * cnt) >> 32)-th valid action in L,R,U,D order (cnt == 0 -> 0);
+ * unmasked: action = word & 3.   actions: uint8[M]; logp: float[M] or NULL.
+ */
+int ml2048_sample_actions(void *stream, int64_t M, int64_t idx_base, const uint8_t *valid,
+                          uint64_t seed, uint64_t counter, int masked, uint8_t *actions,
+                          float *logp);
+
+/*
+ * Observation encode (CNNEncoder.forward's first lines, src/ml2048/policy/_network.py:91-95,105):
+ * onehot[n][k][r][c] = (board[n][4r+c] == k), k < 16, float32, contiguous (M,16,4,4).
+ * board_i64 (or NULL): the (M,16) int64 tensor the reference network asserts as input (:87-88).
+ * bad_count (or NULL): device int32, incremented by the number of cells with exponent >= 16,
+ * which the reference cannot encode (F.one_hot raises; NUM_CLASSES = 16, _network.py:8).
+ */
+int ml2048_encode_onehot(void *stream, int64_t M, const uint8_t *board, float *onehot,
+                         int64_t *board_i64, int32_t *bad_count);
+
+/*
+ * Max-tile histogram: counts[max(board[i])] += 1 for every board with terminated[i] != 0
+ * (`_update_count`, src/ml2048/runner.py:120-136), or for every board when terminated is NULL
+ * (the histogram behind VecGame.summary, game_numba.py:593-604).  counts: device int32[20],
+ * accumulated into (not cleared).
+ */
+int ml2048_hist_maxcell(void *stream, int64_t M, const uint8_t *board, const uint8_t *terminated,
+                        int32_t *counts);
+
+/* SoA <-> the reference's 64-byte array-of-records (`VecGame._data`, game_numba.py:537-551,
+ * :571) for callers that read `env._data` (src/ml2048/replay.py:147-151).  records: [M][64]. */
+int ml2048_pack_records(void *stream, int64_t M, const ml2048_state *st, void *records);
+int ml2048_unpack_records(void *stream, int64_t M, const ml2048_state *st, const void *records);
+
+/* Order-independent 64-bit digest of all record fields of all boards (with_id = 0: all but
+ * `id`), ADDED to *out (device uint64).  Same function as oracle orc_digest; used for
+ * full-size parity checks. */
+int ml2048_digest(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int with_id,
+                  uint64_t *out);
+
+/* Test hook: out[4*i..] = the 4 words rocRAND's Philox generator yields for
+ * (seed, subsequence = idx_base + i, offset = 4 * counter); must equal Philox4x32-10 of
+ * counter {counter, idx_base + i}, key seed. */
+int ml2048_debug_philox(void *stream, int64_t n, int64_t idx_base, uint64_t seed, uint64_t counter,
+                        uint32_t *out);
+
+/*
+ * Fused N-step rollout with on-device action sampling: the random-action loop
+ *     for t in range(N): env.prepare(); a = policy.sample_actions(...); env.step(a)
+ * (VecRunner.step_many with RandomPolicy, src/ml2048/runner.py:74-117, policy/random.py:17-27)
+ * as ONE launch, every board resident in registers for all N steps; bit-exact with N calls of
+ * ml2048_prepare / ml2048_sample_actions / ml2048_step on the same host RNG schedule.
+ *   perm_epochs   device uint8[n_epochs][1024][16]: the successive `_randperm` tables
+ *   two_masks     device uint32[n_epochs]: bit c <=> float64(randfloat[c]) < two_prob (H1: only
+ *                 randfloat[0..15] are ever read, game_numba.py:207)
+ *   schedule      device int32[N][3]: {table epoch, row_base of prepare, row_base of step} - the
+ *                 host PCG64 draw order (:622-626, :670) does not depend on game state, so the
+ *                 host pre-draws it for N steps
+ *   sampler       as ml2048_sample_actions with counter = act_counter0 + t
+ *   actions_out   device uint8[N][M] or NULL: the sampled actions (to replay on an oracle)
+ *   digests_out   device uint64[N] or NULL: per-step digest of every field except `id`, ADDED to
+ *   reset_flags   device uint64[N][ml2048_rollout_flag_words(M)]: bit = board was re-dealt by
+ *                 step t's prepare;  last_reset: device int32[M] out, last t a board was dealt (-1)
+ * `id` is left untouched by this launch: the reference numbers new games in ascending
+ * (step, slot) order (game_numba.py:641-644), a device-wide ordered scan per step.  That scan is
+ * done once, after the fact, by ml2048_rollout_finish_ids from reset_flags/last_reset.
+ */
+int64_t ml2048_rollout_flag_words(int64_t M);
+int64_t ml2048_rollout_scratch_ints(int64_t M, int32_t N);
+int ml2048_rollout(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
+                   const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,
+                   const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed,
+                   uint64_t act_counter0, uint8_t *actions_out, uint64_t *digests_out,
+                   uint64_t *reset_flags, int32_t *last_reset);
+/* ids for the boards dealt during a rollout + *game_count advanced by the total; step_resets:
+ * device int32[N] out or NULL (boards dealt per step = len(prepare()[0]) of each step);
+ * scratch: device int32[ml2048_rollout_scratch_ints(M, N)]. */
+int ml2048_rollout_finish_ids(void *stream, int64_t M, const ml2048_state *st, int32_t N,
+                              const uint64_t *reset_flags, const int32_t *last_reset,
+                              int32_t *game_count, int32_t *step_resets, int32_t *scratch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,98 @@
+"""ctypes binding of libml2048_hip.so (include/ml2048_hip.h).
+
+The product has exactly one compute path: the HIP library.  If it is missing or cannot be loaded
+this module raises - there is no CPU or PyTorch fallback anywhere in the package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+LIB_PATH = _build.LIB_PATH
+
+
+class State(C.Structure):
+    """struct ml2048_state (include/ml2048_hip.h)."""
+
+    _fields_ = [(n, C.c_void_p) for n in (
+        "board", "merged", "valid", "step", "score", "reward", "terminated", "invalid", "id",
+        "prev_board", "prev_valid")]
+
+
+class Ml2048Error(RuntimeError):
+    pass
+
+
+_lib = None
+
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "ml2048_abi_version": (C.c_int, []),
+    "ml2048_last_error": (C.c_char_p, []),
+    "ml2048_scratch_ints": (C.c_int64, [C.c_int64]),
+    "ml2048_reset": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(State)]),
+    "ml2048_prepare": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_void_p, C.c_void_p,
+                                 C.c_double, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ml2048_step": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_void_p, C.c_int, C.c_int,
+                              C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ml2048_prepare_fast": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_double, C.c_uint64,
+                                      C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ml2048_step_fast": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_void_p, C.c_int, C.c_int,
+                                   C.c_double, C.c_uint64, C.c_uint64]),
+    "ml2048_sample_actions": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_uint64, C.c_uint64,
+                                        C.c_int, C.c_void_p, C.c_void_p]),
+    "ml2048_encode_onehot": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ml2048_hist_maxcell": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ml2048_pack_records": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(State), C.c_void_p]),
+    "ml2048_unpack_records": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(State), C.c_void_p]),
+    "ml2048_digest": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_int, C.c_void_p]),
+    "ml2048_debug_philox": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "ml2048_rollout_flag_words": (C.c_int64, [C.c_int64]),
+    "ml2048_rollout_scratch_ints": (C.c_int64, [C.c_int64, C.c_int32]),
+    "ml2048_rollout": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_int32, C.c_void_p,
+                                 C.c_void_p, C.c_int32, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ml2048_rollout_finish_ids": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(State), C.c_int32, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+def load(path: str | None = None) -> C.CDLL:
+    """Load (once) and bind the HIP library; raises Ml2048Error when it is not there."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise Ml2048Error(
+            f"{p} not found: build the HIP extension first (python -m ml2048_amd.build). "
+            "ml2048_amd has no CPU fallback."
+        )
+    try:
+        L = C.CDLL(p)
+    except OSError as e:  # pragma: no cover - depends on the box
+        raise Ml2048Error(f"cannot load {p}: {e}") from e
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if L.ml2048_abi_version() != 1:
+        raise Ml2048Error(f"ABI version {L.ml2048_abi_version()} != 1")
+    if path is None:
+        _lib = L
+    return L
+
+
+def check(rc: int, what: str = "") -> None:
+    """Map the C ABI's error convention onto Python exceptions (ValueError for bad arguments,
+    like the reference's own argument checks; RuntimeError for HIP failures)."""
+    if rc == 0:
+        return
+    msg = load().ml2048_last_error().decode("utf-8", "replace")
+    if rc < 0:
+        raise ValueError(f"{what}: {msg} (code {rc})")
+    raise Ml2048Error(f"{what}: {msg} (hipError {rc})")

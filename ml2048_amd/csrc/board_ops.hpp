@@ -1,0 +1,407 @@
+// board_ops.hpp - per-board 2048 arithmetic for gfx950, one board per lane, SIMD-within-register.
+//
+// A board is 16 uint8 tile exponents (0 = empty, k = tile 2^k; reference layout
+// src/ml2048/game_numba.py:13-20, :542) held as four 32-bit row words: r[i] byte j = cell 4i+j.
+// All game logic is branch-free byte-parallel integer work on those four VGPRs (no MFMA: this is
+// indexing work, not a contraction).  Exponents are < 0x80, which the carry-free byte tests below
+// rely on (the reference's tiles top out at 17, ITEM_VALUES game_numba.py:23-45).
+//
+// The functions are plain C++ so that tests/csrc/host_ops_harness.cpp can compile this very file
+// with g++ and check the bit tricks exhaustively on the CPU (a test harness, not a product path);
+// on the device `perm_b32` lowers to one v_perm_b32.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define ML_HD __host__ __device__ __forceinline__
+#else
+#define ML_HD inline
+#endif
+
+namespace ml2048 {
+
+struct Board {
+    uint32_t r[4];
+};
+
+// ---- byte shuffles ---------------------------------------------------------------------------
+// v_perm_b32 semantics: pool = {hi:bytes 4-7, lo:bytes 0-3}; selector byte 0x0c yields 0x00.
+ML_HD uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    uint64_t pool = ((uint64_t)hi << 32) | lo;
+    uint32_t out = 0;
+    for (int i = 0; i < 4; ++i) {
+        uint32_t s = (sel >> (8 * i)) & 0xFF;
+        uint32_t b = (s < 8) ? (uint32_t)((pool >> (8 * s)) & 0xFF) : (s == 0x0c ? 0u : 0xFFu);
+        out |= b << (8 * i);
+    }
+    return out;
+#endif
+}
+
+ML_HD uint32_t bswap32(uint32_t x) { return perm_b32(0, x, 0x00010203u); }
+
+// 0x80 in every byte of x that is non-zero (bytes must be <= 0x80)
+ML_HD uint32_t nz_bytes(uint32_t x) { return (x + 0x7F7F7F7Fu) & 0x80808080u; }
+// 0x80 in every byte of x that is zero
+ML_HD uint32_t z_bytes(uint32_t x) { return ~(x + 0x7F7F7F7Fu) & 0x80808080u; }
+// gather the four 0x80 flags of a byte mask into bits 0..3
+ML_HD uint32_t flags4(uint32_t m80) { return (((m80 >> 7) * 0x00204081u) >> 21) & 0xFu; }
+
+// 4x4 byte transpose (an involution): 8 v_perm_b32
+ML_HD Board transpose(const Board &b) {
+    // interleave bytes of (r0,r1) and (r2,r3)
+    uint32_t a_lo = perm_b32(b.r[1], b.r[0], 0x05010400u); // r0.b0 r1.b0 r0.b1 r1.b1
+    uint32_t a_hi = perm_b32(b.r[1], b.r[0], 0x07030602u); // r0.b2 r1.b2 r0.b3 r1.b3
+    uint32_t c_lo = perm_b32(b.r[3], b.r[2], 0x05010400u);
+    uint32_t c_hi = perm_b32(b.r[3], b.r[2], 0x07030602u);
+    Board t;
+    t.r[0] = perm_b32(c_lo, a_lo, 0x05040100u); // a_lo.lo16 | c_lo.lo16
+    t.r[1] = perm_b32(c_lo, a_lo, 0x07060302u); // a_lo.hi16 | c_lo.hi16
+    t.r[2] = perm_b32(c_hi, a_hi, 0x05040100u);
+    t.r[3] = perm_b32(c_hi, a_hi, 0x07060302u);
+    return t;
+}
+
+// ---- one line, pushed toward byte 0 (reference _push_row, game_numba.py:48-90) ---------------
+// Returns the new line; mexp gets the pre-merge exponents of the (at most two) merges in
+// bytes 0 and 1 (0 = no merge): exactly the indices `buckets[num] += 1` touches (:76).
+ML_HD uint32_t push_line(uint32_t x, uint32_t &mexp) {
+    // stable compaction of the non-zero bytes toward byte 0, high end first
+    uint32_t s2 = perm_b32(0, x, 0x0c030100u); // drop byte 2
+    x = (x & 0x00FF0000u) ? x : s2;
+    uint32_t s1 = perm_b32(0, x, 0x0c030200u); // drop byte 1
+    x = (x & 0x0000FF00u) ? x : s1;
+    x = (x & 0x000000FFu) ? x : (x >> 8);
+    // equal neighbours among the compacted bytes c0..c3
+    uint32_t e = z_bytes(x ^ (x >> 8)) & nz_bytes(x); // 0x80 at byte i  <=>  c_i == c_{i+1} != 0
+    bool e01 = (e & 0x00000080u) != 0;
+    bool e12 = (e & 0x00008000u) != 0;
+    bool e23 = (e & 0x00800000u) != 0;
+    uint32_t c0 = x & 0xFFu, c1 = (x >> 8) & 0xFFu, c2 = (x >> 16) & 0xFFu;
+    // e01: [c0+1, c2, c3, 0]; and e23 on top: [c0+1, c2+1, 0, 0]
+    uint32_t rB = perm_b32(0, x, 0x0c030200u) + 0x00000001u;
+    uint32_t rA = (rB & 0x0000FFFFu) + 0x00000100u;
+    // e12 alone: [c0, c1+1, c3, 0]
+    uint32_t rC = perm_b32(0, x, 0x0c030100u) + 0x00000100u;
+    // e23 alone: [c0, c1, c2+1, 0]
+    uint32_t rD = (x & 0x00FFFFFFu) + 0x00010000u;
+    uint32_t res = e01 ? (e23 ? rA : rB) : (e12 ? rC : (e23 ? rD : x));
+    uint32_t m_first = e01 ? c0 : (e12 ? c1 : (e23 ? c2 : 0u));
+    uint32_t m_second = (e01 && e23) ? c2 : 0u;
+    mexp = m_first | (m_second << 8);
+    return res;
+}
+
+struct MoveResult {
+    Board board;
+    uint32_t mexp_first;  // byte j = exponent of the first merge in line j (0 = none)
+    uint32_t mexp_second; // byte j = exponent of the second merge in line j
+};
+
+// reference _step_kernel (game_numba.py:93-134): L (0,+1) R (3,-1) U (0,+4) D (12,-4)
+ML_HD MoveResult move_board(const Board &in, uint32_t action) {
+    const bool vertical = (action & 2u) != 0;
+    const bool reverse = (action & 1u) != 0;
+    Board b = in;
+    if (vertical) b = transpose(b);
+    MoveResult out;
+    out.mexp_first = 0;
+    out.mexp_second = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t x = b.r[j];
+        x = reverse ? bswap32(x) : x;
+        uint32_t m;
+        x = push_line(x, m);
+        x = reverse ? bswap32(x) : x;
+        b.r[j] = x;
+        out.mexp_first |= (m & 0xFFu) << (8 * j);
+        out.mexp_second |= (m >> 8) << (8 * j);
+    }
+    if (vertical) b = transpose(b);
+    out.board = b;
+    return out;
+}
+
+// ---- merged[16] bucket counters (the record's `merged` field) ---------------------------------
+// merged[num] += 1 for num in 1..15; num >= 16 is the reference's out-of-bounds write (H9) whose
+// target byte is rewritten by _compute_valid_actions before anything reads it, so it is dropped.
+ML_HD void add_bucket(uint32_t m[4], uint32_t num) {
+    uint32_t ok = (num - 1u) < 15u;
+    uint32_t inc = ok << ((num & 3u) * 8u);
+    uint32_t d = num >> 2;
+    m[0] += (d == 0u) ? inc : 0u;
+    m[1] += (d == 1u) ? inc : 0u;
+    m[2] += (d == 2u) ? inc : 0u;
+    m[3] += (d == 3u) ? inc : 0u;
+}
+
+struct MergeStats {
+    uint32_t merged[4]; // 16 byte counters
+    uint32_t sum_value; // sum 2^(num+1)      -> reward_fn_normal (game_numba.py:408-438)
+    uint32_t sum_rank;  // sum (num+1)        -> reward_fn_rank   (:469-484)
+    uint32_t count;     // number of merges   -> merged.sum() in reward_fn_maxcell (:502)
+};
+
+ML_HD MergeStats merge_stats(uint32_t mexp_first, uint32_t mexp_second) {
+    MergeStats s;
+    s.merged[0] = s.merged[1] = s.merged[2] = s.merged[3] = 0;
+    s.sum_value = s.sum_rank = s.count = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        uint32_t word = (k < 4) ? mexp_first : mexp_second;
+        uint32_t num = (word >> (8 * (k & 3))) & 0xFFu;
+        add_bucket(s.merged, num);
+        uint32_t ok = (num - 1u) < 15u;
+        s.sum_value += ok ? (2u << num) : 0u;
+        s.sum_rank += ok ? (num + 1u) : 0u;
+        s.count += ok;
+    }
+    return s;
+}
+
+// ---- valid-action mask (reference _line_movable / _compute_valid_actions, :215-289) -----------
+// forward  (toward index 0)  <=> exists i: n[i+1] != 0 and (n[i] == 0 or n[i] == n[i+1])
+// backward (toward index 3)  <=> exists i: n[i]   != 0 and (n[i+1] == 0 or n[i] == n[i+1])
+// returns bytes {left, right, up, down} as 0/1 in byte 0..3 - the record's valid_actions word.
+ML_HD uint32_t valid_actions(const Board &b) {
+    uint32_t nz[4], zz[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        nz[i] = nz_bytes(b.r[i]);
+        zz[i] = nz[i] ^ 0x80808080u;
+    }
+    uint32_t left = 0, right = 0, up = 0, down = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { // rows: neighbour of byte j is byte j+1
+        uint32_t a = b.r[i], n = a >> 8;
+        uint32_t eq = z_bytes(a ^ n);
+        uint32_t nz_n = nz[i] >> 8, z_n = (zz[i] >> 8) | 0x80000000u;
+        left |= nz_n & (zz[i] | eq);
+        right |= nz[i] & (z_n | eq) & 0x00808080u;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { // columns: neighbour of row i is row i+1, 4 columns at once
+        uint32_t eq = z_bytes(b.r[i] ^ b.r[i + 1]);
+        up |= nz[i + 1] & (zz[i] | eq);
+        down |= nz[i] & (zz[i + 1] | eq);
+    }
+    left &= 0x00808080u;
+    return (left ? 1u : 0u) | (right ? 0x100u : 0u) | (up ? 0x10000u : 0u) | (down ? 0x1000000u : 0u);
+}
+
+// bit c set <=> cell c is empty
+ML_HD uint32_t empty_mask(const Board &b) {
+    uint32_t m = flags4(nz_bytes(b.r[0])) | (flags4(nz_bytes(b.r[1])) << 4) |
+                 (flags4(nz_bytes(b.r[2])) << 8) | (flags4(nz_bytes(b.r[3])) << 12);
+    return ~m & 0xFFFFu;
+}
+
+ML_HD void set_cell(Board &b, uint32_t cell, uint32_t value) {
+    uint32_t v = value << ((cell & 3u) * 8u);
+    uint32_t d = cell >> 2;
+    b.r[0] |= (d == 0u) ? v : 0u;
+    b.r[1] |= (d == 1u) ? v : 0u;
+    b.r[2] |= (d == 2u) ? v : 0u;
+    b.r[3] |= (d == 3u) ? v : 0u;
+}
+
+// ---- table-driven spawn, bit-exact with the reference (_spawn2, game_numba.py:172-212) --------
+// perm = one row of randperm (16 cell indices); two_mask bit c <=> float64(randfloat[c]) < two_prob
+// (randfloat is indexed by the CELL, :207, hazard H1).  Places up to `count` tiles.
+ML_HD void spawn_table(Board &b, const uint32_t perm[4], uint32_t two_mask, int count) {
+    const uint32_t empties = empty_mask(b);
+    const uint64_t plo = (uint64_t)perm[0] | ((uint64_t)perm[1] << 32);
+    const uint64_t phi = (uint64_t)perm[2] | ((uint64_t)perm[3] << 32);
+    uint32_t hits = 0; // bit i <=> cell perm[i] is empty
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        uint32_t c = (perm[i >> 2] >> (8 * (i & 3))) & 0xFu;
+        hits |= ((empties >> c) & 1u) << i;
+    }
+    for (int n = 0; n < count; ++n) {
+        if (hits == 0) break;
+        uint32_t i = (uint32_t)__builtin_ctz(hits);
+        hits &= hits - 1u;
+        uint64_t half = (i & 8u) ? phi : plo;
+        uint32_t c = (uint32_t)(half >> (8u * (i & 7u))) & 0xFu;
+        set_cell(b, c, ((two_mask >> c) & 1u) ? 1u : 2u);
+    }
+}
+
+// ---- counter-based spawn (fast mode; build-defined, equals oracle orc_step_fast) --------------
+// cell = k-th empty cell in ascending order, k = (a * n_empty) >> 32; tile 1 if b < thr else 2.
+ML_HD void spawn_counter(Board &b, uint32_t a, uint32_t bword, uint64_t thr) {
+    uint32_t empties = empty_mask(b);
+    uint32_t n_empty = (uint32_t)__builtin_popcount(empties);
+    if (n_empty == 0) return;
+    uint32_t k = (uint32_t)(((uint64_t)a * n_empty) >> 32);
+    // k-th set bit: clear the k lowest set bits, then ctz
+    uint32_t m = empties;
+    for (uint32_t j = 0; j < k; ++j) m &= m - 1u;
+    uint32_t c = (uint32_t)__builtin_ctz(m);
+    set_cell(b, c, ((uint64_t)bword < thr) ? 1u : 2u);
+}
+
+ML_HD uint32_t max_cell(const Board &b) {
+    uint32_t mx = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t v = (b.r[i] >> (8 * j)) & 0xFFu;
+            mx = v > mx ? v : mx;
+        }
+    return mx;
+}
+
+enum { REWARD_NORMAL = 0, REWARD_IMPROVED = 1, REWARD_RANK = 2, REWARD_MAXCELL = 3 };
+
+// reference reward functions at numba's typing (int64 sums, then float64), game_numba.py:408-504
+ML_HD double reward_value(int kind, const Board &state, const Board &prev, const MergeStats &s) {
+    switch (kind) {
+    default:
+    case REWARD_NORMAL:
+        return (double)s.sum_value;
+    case REWARD_IMPROVED: {
+        uint32_t p0 = prev.r[0] & 0xFFu, s0 = state.r[0] & 0xFFu;
+        int64_t extra = 0;
+        if (p0 != 0) extra -= (int64_t)64 << p0;
+        if (s0 != 0) extra += (int64_t)64 << s0;
+        return (double)s.sum_value + (double)extra;
+    }
+    case REWARD_RANK:
+        return (double)s.sum_rank;
+    case REWARD_MAXCELL: {
+        uint32_t cur = max_cell(state), prv = max_cell(prev);
+        double r = 0.0;
+        if (cur > prv) r += (double)((int64_t)1 << cur);
+        return r + (double)s.count;
+    }
+    }
+}
+
+// ---- one board of the reference's _vec_step loop body (game_numba.py:716-738) ------------------
+// Split around the spawn so that the table-driven and counter-based spawns share it.
+// Returns false for an invalid move: the caller then writes only invalid=1 (hazard H3).
+struct StepRegs {
+    Board board;
+    uint32_t valid;      // valid_actions word (4 x 0/1 bytes)
+    int32_t step;
+    float score;
+    float reward;        // written only on a valid move
+    uint32_t merged[4];  // written only on a valid move
+    uint32_t terminated; // written only on a valid move
+};
+
+ML_HD bool step_pre(StepRegs &s, uint32_t action, int reward_kind) {
+    // H11: an out-of-range action is treated as invalid (the reference would read out of bounds)
+    bool ok = action < 4u && ((s.valid >> (8u * (action & 3u))) & 0xFFu) != 0u;
+    if (!ok) return false;
+    Board prev = s.board;
+    MoveResult mv = move_board(prev, action);
+    MergeStats st = merge_stats(mv.mexp_first, mv.mexp_second);
+    s.board = mv.board;
+    s.merged[0] = st.merged[0];
+    s.merged[1] = st.merged[1];
+    s.merged[2] = st.merged[2];
+    s.merged[3] = st.merged[3];
+    s.step += 1;
+    s.reward = (float)reward_value(reward_kind, mv.board, prev, st);
+    // score accumulates reward_fn_normal whatever reward_fn is (:729-731); f32+f64 -> f32 (H8)
+    s.score = (float)((double)s.score + (double)st.sum_value);
+    return true;
+}
+
+ML_HD void step_post(StepRegs &s) {
+    s.valid = valid_actions(s.board);
+    s.terminated = s.valid == 0u;
+}
+
+// a freshly dealt game (VecGame.prepare's loop body, game_numba.py:638-656) before its two spawns
+ML_HD void clear_regs(StepRegs &s) {
+    s.board.r[0] = s.board.r[1] = s.board.r[2] = s.board.r[3] = 0;
+    s.merged[0] = s.merged[1] = s.merged[2] = s.merged[3] = 0;
+    s.valid = 0;
+    s.step = 0;
+    s.score = 0.0f;
+    s.reward = 0.0f;
+    s.terminated = 0;
+}
+
+// ---- Philox4x32-10 (hand-written form; the kernels' default path uses the rocRAND device API,
+//      which tests/test_gpu_parity.py checks word-for-word against this and the oracle) --------
+struct U4 {
+    uint32_t x, y, z, w;
+};
+
+ML_HD U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
+        U4 n;
+        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+        n.y = (uint32_t)p1;
+        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+        n.w = (uint32_t)p0;
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+ML_HD U4 philox_at(uint64_t seed, uint64_t counter, uint64_t idx) {
+    U4 c = {(uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)idx, (uint32_t)(idx >> 32)};
+    return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// masked-uniform / uniform action from one random word (oracle orc_sample_actions)
+ML_HD uint32_t pick_action(uint32_t valid_word, uint32_t word, int masked, uint32_t &cnt_out) {
+    if (!masked) {
+        cnt_out = 4;
+        return word & 3u;
+    }
+    uint32_t bits = flags4(nz_bytes(valid_word));
+    uint32_t cnt = (uint32_t)__builtin_popcount(bits);
+    cnt_out = cnt;
+    if (cnt == 0) return 0;
+    uint32_t k = (uint32_t)(((uint64_t)word * cnt) >> 32);
+    for (uint32_t j = 0; j < k; ++j) bits &= bits - 1u;
+    return (uint32_t)__builtin_ctz(bits);
+}
+
+ML_HD float neg_log_count(uint32_t cnt) {
+    // -ln(cnt) as float32 literals (shared with the oracle so CPU and GPU agree bit for bit)
+    return cnt == 4 ? -1.38629436111989f : cnt == 3 ? -1.09861228866811f
+         : cnt == 2 ? -0.693147180559945f : 0.0f;
+}
+
+// 64-bit order-independent per-board digest (oracle orc_digest)
+ML_HD uint64_t mix_word(uint64_t h, uint64_t w) {
+    h = (h ^ w) * 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 29;
+    return h;
+}
+
+// id < 0 in `with_id == 0` calls is simply not mixed in
+ML_HD uint64_t board_digest(uint64_t global_idx, const Board &b, const uint32_t merged[4], uint32_t valid,
+                            uint32_t terminated, uint32_t invalid, int32_t step, int32_t id,
+                            uint32_t score_bits, uint32_t reward_bits, int with_id = 1) {
+    uint64_t h = 0x9E3779B97F4A7C15ull * (global_idx + 1);
+    h = mix_word(h, (uint64_t)b.r[0] | ((uint64_t)b.r[1] << 32));
+    h = mix_word(h, (uint64_t)b.r[2] | ((uint64_t)b.r[3] << 32));
+    h = mix_word(h, (uint64_t)merged[0] | ((uint64_t)merged[1] << 32));
+    h = mix_word(h, (uint64_t)merged[2] | ((uint64_t)merged[3] << 32));
+    h = mix_word(h, (uint64_t)valid | ((uint64_t)(terminated & 0xFFu) << 32) | ((uint64_t)(invalid & 0xFFu) << 40));
+    h = mix_word(h, (uint64_t)(uint32_t)step);
+    h = mix_word(h, (uint64_t)score_bits | ((uint64_t)reward_bits << 32));
+    if (with_id) h = mix_word(h, (uint64_t)(uint32_t)id);
+    return h;
+}
+
+} // namespace ml2048

@@ -1,0 +1,853 @@
+// ml2048_hip.hip - gfx950 (MI355X) kernels + the C ABI of include/ml2048_hip.h.
+//
+// Mapping: one board per lane (64 boards per wavefront).  A board is 16 bytes, so a wave's
+// load/store of any 16-byte field is one fully coalesced 1 KiB global_load/store_dwordx4 and the
+// 4-byte fields are one 256-byte dword access; all game logic is register-resident byte-parallel
+// integer work (board_ops.hpp).  The work is HBM-bound integer/byte work: no MFMA anywhere.
+// The one-hot encoder alone uses the wave-per-board mapping: the fp32 one-hot of one board is
+// exactly 64 lanes x 16 B, one dwordx4 store per lane per board.
+#include <hip/hip_runtime.h>
+#include <rocrand/rocrand_kernel.h>
+
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ml2048_hip.h"
+#include "board_ops.hpp"
+
+using namespace ml2048;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, "%s: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+constexpr int kBlock = 256;      // threads per workgroup for the per-board kernels (4 waves)
+constexpr int kPrepBlock = 1024; // boards per workgroup in the prepare scan
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+int check_state(int64_t M, const ml2048_state *st) {
+    if (M <= 0) return fail(ML2048_E_INVALID, "M=%lld must be positive", (long long)M);
+    if (M > (int64_t)1 << 31) return fail(ML2048_E_INVALID, "M=%lld too large", (long long)M);
+    if (!st) return fail(ML2048_E_INVALID, "state is NULL");
+    const void *p[] = {st->board, st->merged, st->valid, st->step, st->score, st->reward,
+                       st->terminated, st->invalid, st->id, st->prev_board, st->prev_valid};
+    const char *n[] = {"board", "merged", "valid", "step", "score", "reward",
+                       "terminated", "invalid", "id", "prev_board", "prev_valid"};
+    const unsigned al[] = {16, 16, 4, 4, 4, 4, 1, 1, 4, 16, 4};
+    for (int i = 0; i < 11; ++i) {
+        if (!p[i]) return fail(ML2048_E_INVALID, "state.%s is NULL", n[i]);
+        if ((uintptr_t)p[i] % al[i]) return fail(ML2048_E_ALIGN, "state.%s must be %u-byte aligned", n[i], al[i]);
+    }
+    return 0;
+}
+
+// ---- device helpers --------------------------------------------------------------------------
+__device__ __forceinline__ Board load_board(const uint8_t *base, int64_t i) {
+    uint4 v = reinterpret_cast<const uint4 *>(base)[i];
+    Board b;
+    b.r[0] = v.x; b.r[1] = v.y; b.r[2] = v.z; b.r[3] = v.w;
+    return b;
+}
+
+__device__ __forceinline__ void store16(uint8_t *base, int64_t i, const uint32_t w[4]) {
+    reinterpret_cast<uint4 *>(base)[i] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ uint32_t load_action(const void *actions, int dtype, int64_t i) {
+    if (dtype == ML2048_ACT_U8) return reinterpret_cast<const uint8_t *>(actions)[i];
+    if (dtype == ML2048_ACT_I32) return (uint32_t) reinterpret_cast<const int32_t *>(actions)[i];
+    int64_t a = reinterpret_cast<const int64_t *>(actions)[i];
+    return (a < 0 || a > 3) ? 0xFFFFFFFFu : (uint32_t)a;
+}
+
+// bit c <=> float64(randfloat[c]) < two_prob for the 16 cells (game_numba.py:207; H1, H2)
+__device__ __forceinline__ uint32_t two_mask_from_table(const float *randfloat, double two_prob) {
+    const int lane = threadIdx.x & 63;
+    float f = randfloat[lane & 15];
+    unsigned long long m = __ballot((double)f < two_prob);
+    return (uint32_t)(m & 0xFFFFull);
+}
+
+__device__ __forceinline__ void load_perm_row(const uint8_t *randperm, int64_t row, uint32_t perm[4]) {
+    uint4 v = reinterpret_cast<const uint4 *>(randperm)[row & (ML2048_RAND_SIZE - 1)];
+    perm[0] = v.x; perm[1] = v.y; perm[2] = v.z; perm[3] = v.w;
+}
+
+// rocRAND Philox4x32-10 device generator: words of (seed, subsequence = idx, offset = 4*counter)
+__device__ __forceinline__ void rocrand_words(uint64_t seed, uint64_t counter, uint64_t idx, uint32_t w[4]) {
+    rocrand_state_philox4x32_10 s;
+    rocrand_init(seed, idx, counter * 4ull, &s);
+    uint4 v = rocrand4(&s);
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+}
+
+__device__ __forceinline__ uint32_t rocrand_word0(uint64_t seed, uint64_t counter, uint64_t idx) {
+    rocrand_state_philox4x32_10 s;
+    rocrand_init(seed, idx, counter * 4ull, &s);
+    return rocrand(&s);
+}
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v; // lane 0 holds the sum
+}
+
+// ---- reset -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_reset(ml2048_state st, int64_t M) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= M) return;
+    const uint32_t z[4] = {0, 0, 0, 0};
+    store16(st.board, i, z);
+    store16(st.merged, i, z);
+    store16(st.prev_board, i, z);
+    reinterpret_cast<uint32_t *>(st.valid)[i] = 0;
+    reinterpret_cast<uint32_t *>(st.prev_valid)[i] = 0;
+    st.step[i] = 0;
+    st.score[i] = 0.0f;
+    st.reward[i] = 0.0f;
+    st.id[i] = 0;
+    st.terminated[i] = 1; // game_numba.py:614 - the first prepare() deals every game
+    st.invalid[i] = 0;
+}
+
+// ---- step --------------------------------------------------------------------------------------
+// Algorithmic traffic per board: read board 16 + valid 4 + step 4 + score 4 + action 1..8;
+// write prev_board 16 + prev_valid 4 always; on a valid move board 16 + merged 16 + valid 4 +
+// step 4 + score 4 + reward 4 + terminated 1 + invalid 1 (=99 B with a 1-byte action).
+template <int KIND, bool FAST>
+__global__ __launch_bounds__(kBlock) void k_step(ml2048_state st, int64_t M, int64_t idx_base,
+                                                 const void *__restrict__ actions, int action_dtype,
+                                                 double two_prob, int64_t row_base,
+                                                 const uint8_t *__restrict__ randperm,
+                                                 const float *__restrict__ randfloat, uint64_t seed,
+                                                 uint64_t counter, uint64_t thr) {
+    const int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i0 < M;
+    const int64_t i = live ? i0 : M - 1; // tail lanes shadow the last board: loads only, no stores
+
+    // issue every load up front; the 2/4 mask (H1: randfloat is indexed by the CELL, so only
+    // randfloat[0..15] matter) is formed by a wave ballot once the loads are in flight
+    float rf = 0.0f;
+    if (!FAST) rf = randfloat[threadIdx.x & 15];
+    StepRegs s;
+    s.board = load_board(st.board, i);
+    s.valid = reinterpret_cast<const uint32_t *>(st.valid)[i];
+    s.step = st.step[i];
+    s.score = st.score[i];
+    const uint32_t action = load_action(actions, action_dtype, i);
+    uint32_t perm[4] = {0, 0, 0, 0};
+    if (!FAST) load_perm_row(randperm, row_base + idx_base + i, perm);
+    uint32_t two_mask = 0;
+    if (!FAST) two_mask = (uint32_t)(__ballot((double)rf < two_prob) & 0xFFFFull);
+    if (!live) return;
+
+    // VecGame.step's copies (game_numba.py:672-673): always, valid move or not
+    store16(st.prev_board, i, s.board.r);
+    reinterpret_cast<uint32_t *>(st.prev_valid)[i] = s.valid;
+
+    if (!step_pre(s, action, KIND)) {
+        st.invalid[i] = 1; // :738
+        return;
+    }
+    if (FAST) {
+        uint32_t w[4];
+        rocrand_words(seed, counter, (uint64_t)(idx_base + i), w);
+        spawn_counter(s.board, w[0], w[1], thr);
+    } else {
+        spawn_table(s.board, perm, two_mask, 1);
+    }
+    step_post(s);
+
+    store16(st.board, i, s.board.r);
+    store16(st.merged, i, s.merged);
+    reinterpret_cast<uint32_t *>(st.valid)[i] = s.valid;
+    st.step[i] = s.step;
+    st.score[i] = s.score;
+    st.reward[i] = s.reward;
+    st.terminated[i] = (uint8_t)s.terminated;
+    st.invalid[i] = 0;
+}
+
+// ---- prepare: count -> scan -> deal --------------------------------------------------------------
+// scratch layout: [0, nblk) per-block counts -> exclusive prefix; [nblk] total; [nblk+1] snapshot
+// of *game_count taken before any block of the deal kernel can advance it.
+__global__ __launch_bounds__(kPrepBlock) void k_prep_count(const uint8_t *__restrict__ terminated,
+                                                           int64_t M, int32_t *__restrict__ scratch) {
+    __shared__ int wave_cnt[kPrepBlock / 64];
+    const int64_t i = (int64_t)blockIdx.x * kPrepBlock + threadIdx.x;
+    const bool t = i < M && terminated[i] != 0;
+    const unsigned long long b = __ballot(t);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[wave] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < kPrepBlock / 64; ++w) tot += wave_cnt[w];
+        scratch[blockIdx.x] = tot;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_prep_scan(int32_t *__restrict__ scratch, int nblk,
+                                                    const int32_t *__restrict__ game_count) {
+    __shared__ int wave_tot[16];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 1024) {
+        const int j = base + threadIdx.x;
+        const int v = j < nblk ? scratch[j] : 0;
+        int incl = v; // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int n = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += n;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int wave_base = 0;
+        for (int w = 0; w < wave; ++w) wave_base += wave_tot[w];
+        const int carry = carry_s;
+        if (j < nblk) scratch[j] = carry + wave_base + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + wave_base + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        scratch[nblk] = carry_s;
+        scratch[nblk + 1] = *game_count;
+    }
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(kPrepBlock) void k_prep_deal(ml2048_state st, int64_t M, int64_t idx_base,
+                                                          const uint8_t *__restrict__ randperm,
+                                                          const float *__restrict__ randfloat,
+                                                          double two_prob, int64_t row_base,
+                                                          uint64_t seed, uint64_t counter, uint64_t thr,
+                                                          const int32_t *__restrict__ scratch, int nblk,
+                                                          int32_t *__restrict__ game_count,
+                                                          int32_t *__restrict__ n_reset,
+                                                          int64_t *__restrict__ reset_indices) {
+    __shared__ int wave_cnt[kPrepBlock / 64];
+    uint32_t two_mask = 0;
+    if (!FAST) two_mask = two_mask_from_table(randfloat, two_prob);
+    const int total = scratch[nblk];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *n_reset = total;
+        *game_count = scratch[nblk + 1] + total; // only this thread writes it; readers use the snapshot
+    }
+    if (total == 0) return;
+    const int64_t i = (int64_t)blockIdx.x * kPrepBlock + threadIdx.x;
+    const bool t = i < M && st.terminated[i] != 0;
+    const unsigned long long b = __ballot(t);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[wave] = __popcll(b);
+    __syncthreads();
+    if (!t) return;
+    int rank = scratch[blockIdx.x] + __popcll(b & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) rank += wave_cnt[w];
+
+    StepRegs s;
+    clear_regs(s); // entry.fill(0), game_numba.py:639
+    if (FAST) {
+        uint32_t w[4];
+        rocrand_words(seed, counter, (uint64_t)(idx_base + i), w);
+        spawn_counter(s.board, w[0], w[1], thr);
+        spawn_counter(s.board, w[2], w[3], thr);
+    } else {
+        uint32_t perm[4];
+        load_perm_row(randperm, row_base + idx_base + i, perm);
+        spawn_table(s.board, perm, two_mask, 2); // :648-655
+    }
+    s.valid = valid_actions(s.board); // :656
+
+    store16(st.board, i, s.board.r);
+    store16(st.merged, i, s.merged);
+    reinterpret_cast<uint32_t *>(st.valid)[i] = s.valid;
+    st.step[i] = 0;
+    st.score[i] = 0.0f;
+    st.reward[i] = 0.0f;
+    st.terminated[i] = 0;
+    st.invalid[i] = 0;
+    st.id[i] = scratch[nblk + 1] + rank; // :641-644, ascending slot order
+    if (reset_indices) reset_indices[rank] = i;
+}
+
+// ---- sampler -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_sample(const uint8_t *__restrict__ valid, int64_t M,
+                                                   int64_t idx_base, uint64_t seed, uint64_t counter,
+                                                   int masked, uint8_t *__restrict__ actions,
+                                                   float *__restrict__ logp) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= M) return;
+    const uint32_t v = masked ? reinterpret_cast<const uint32_t *>(valid)[i] : 0x01010101u;
+    const uint32_t word = rocrand_word0(seed, counter, (uint64_t)(idx_base + i));
+    uint32_t cnt;
+    const uint32_t a = pick_action(v, word, masked, cnt);
+    actions[i] = (uint8_t)a;
+    if (logp) logp[i] = neg_log_count(cnt);
+}
+
+__global__ __launch_bounds__(kBlock) void k_debug_philox(int64_t n, int64_t idx_base, uint64_t seed,
+                                                         uint64_t counter, uint32_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w[4];
+    rocrand_words(seed, counter, (uint64_t)(idx_base + i), w);
+    reinterpret_cast<uint4 *>(out)[i] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ---- one-hot observation encode --------------------------------------------------------------------
+// Wave-per-board on the store side: each wave loads 64 boards (one dwordx4 per lane), then for
+// each of them every lane emits the 4 consecutive floats [4*lane, 4*lane+3] of that board's
+// (16,4,4) one-hot = class k = lane>>2, row r = lane&3, columns 0..3: one coalesced 1 KiB
+// global_store_dwordx4 per board.  1 KiB written per 16 B read.
+__global__ __launch_bounds__(kBlock) void k_onehot(const uint8_t *__restrict__ board, int64_t M,
+                                                   float *__restrict__ onehot,
+                                                   int64_t *__restrict__ board_i64,
+                                                   int32_t *__restrict__ bad_count) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_global = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
+    const uint32_t k = (uint32_t)lane >> 2; // class
+    const int r = lane & 3;                 // board row
+    const uint32_t kkkk = k * 0x01010101u;
+    int bad = 0;
+    for (int64_t base = wave_global * 64; base < M; base += n_waves * 64) {
+        const int64_t mine = base + lane;
+        Board b;
+        b.r[0] = b.r[1] = b.r[2] = b.r[3] = 0;
+        if (mine < M) b = load_board(board, mine);
+        if (bad_count) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) // bytes >= 16  <=>  (x & 0xF0) != 0 for exponents < 0x80
+                bad += __popc(nz_bytes(b.r[q] & 0xF0F0F0F0u));
+        }
+        const int cnt = (int)((M - base) < 64 ? (M - base) : 64);
+        for (int j = 0; j < cnt; ++j) {
+            // broadcast board j of this wave (wave-uniform j -> v_readlane_b32)
+            const uint32_t r0 = __builtin_amdgcn_readlane(b.r[0], j);
+            const uint32_t r1 = __builtin_amdgcn_readlane(b.r[1], j);
+            const uint32_t r2 = __builtin_amdgcn_readlane(b.r[2], j);
+            const uint32_t r3 = __builtin_amdgcn_readlane(b.r[3], j);
+            const uint32_t row = r == 0 ? r0 : r == 1 ? r1 : r == 2 ? r2 : r3;
+            const uint32_t eq = z_bytes(row ^ kkkk); // 0x80 where cell == k
+            float4 o;
+            o.x = (eq & 0x00000080u) ? 1.0f : 0.0f;
+            o.y = (eq & 0x00008000u) ? 1.0f : 0.0f;
+            o.z = (eq & 0x00800000u) ? 1.0f : 0.0f;
+            o.w = (eq & 0x80000000u) ? 1.0f : 0.0f;
+            reinterpret_cast<float4 *>(onehot)[(base + j) * 64 + lane] = o;
+        }
+        if (board_i64) {
+            // 64 boards x 16 cells = 1024 int64, written 64 per instruction (512 B, coalesced)
+#pragma unroll 4
+            for (int t = 0; t < 16; ++t) {
+                const int e = t * 64 + lane;   // element within the wave's 64 boards
+                const int src = e >> 4, cell = e & 15;
+                uint32_t w = __shfl(b.r[0], src, 64);
+                const uint32_t w1 = __shfl(b.r[1], src, 64);
+                const uint32_t w2 = __shfl(b.r[2], src, 64);
+                const uint32_t w3 = __shfl(b.r[3], src, 64);
+                const int q = cell >> 2;
+                w = q == 0 ? w : q == 1 ? w1 : q == 2 ? w2 : w3;
+                const int64_t v = (w >> (8 * (cell & 3))) & 0xFFu;
+                if (base + src < M) board_i64[base * 16 + e] = v;
+            }
+        }
+    }
+    if (bad_count) {
+        const uint64_t tot = wave_sum_u64((uint64_t)bad);
+        if (lane == 0 && tot) atomicAdd(bad_count, (int)tot);
+    }
+}
+
+// ---- max-tile histogram ----------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_hist(const uint8_t *__restrict__ board,
+                                                 const uint8_t *__restrict__ terminated, int64_t M,
+                                                 int32_t *__restrict__ counts) {
+    __shared__ int h[20];
+    if (threadIdx.x < 20) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < M; i += (int64_t)gridDim.x * kBlock) {
+        if (terminated && terminated[i] == 0) continue;
+        const Board b = load_board(board, i);
+        const uint32_t mx = max_cell(b);
+        if (mx < 20) atomicAdd(&h[mx], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 20 && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
+}
+
+// ---- AoS <-> SoA -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_pack(ml2048_state st, int64_t M, uint4 *__restrict__ rec) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= M) return;
+    uint4 q0, q3;
+    q0.x = (uint32_t)st.id[i];
+    q0.y = (uint32_t)st.step[i];
+    q0.z = __float_as_uint(st.score[i]);
+    q0.w = __float_as_uint(st.reward[i]);
+    q3.x = reinterpret_cast<const uint32_t *>(st.valid)[i];
+    q3.y = (uint32_t)st.terminated[i] | ((uint32_t)st.invalid[i] << 8);
+    q3.z = 0;
+    q3.w = 0;
+    rec[i * 4 + 0] = q0;
+    rec[i * 4 + 1] = reinterpret_cast<const uint4 *>(st.board)[i];
+    rec[i * 4 + 2] = reinterpret_cast<const uint4 *>(st.merged)[i];
+    rec[i * 4 + 3] = q3;
+}
+
+__global__ __launch_bounds__(kBlock) void k_unpack(ml2048_state st, int64_t M, const uint4 *__restrict__ rec) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= M) return;
+    const uint4 q0 = rec[i * 4 + 0], q3 = rec[i * 4 + 3];
+    st.id[i] = (int32_t)q0.x;
+    st.step[i] = (int32_t)q0.y;
+    st.score[i] = __uint_as_float(q0.z);
+    st.reward[i] = __uint_as_float(q0.w);
+    reinterpret_cast<uint4 *>(st.board)[i] = rec[i * 4 + 1];
+    reinterpret_cast<uint4 *>(st.merged)[i] = rec[i * 4 + 2];
+    reinterpret_cast<uint32_t *>(st.valid)[i] = q3.x;
+    st.terminated[i] = (uint8_t)(q3.y & 0xFFu);
+    st.invalid[i] = (uint8_t)((q3.y >> 8) & 0xFFu);
+}
+
+// ---- digest ----------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_add_u64(uint64_t v, uint64_t *out) {
+    __shared__ uint64_t part[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_sum_u64(v);
+    if (lane == 0) part[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int w = 0; w < kBlock / 64; ++w) t += part[w];
+        atomicAdd(reinterpret_cast<unsigned long long *>(out), (unsigned long long)t);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_digest(ml2048_state st, int64_t M, int64_t idx_base, int with_id,
+                                                   uint64_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    uint64_t h = 0;
+    if (i < M) {
+        const Board b = load_board(st.board, i);
+        const uint4 m = reinterpret_cast<const uint4 *>(st.merged)[i];
+        const uint32_t mm[4] = {m.x, m.y, m.z, m.w};
+        h = board_digest((uint64_t)(idx_base + i), b, mm, reinterpret_cast<const uint32_t *>(st.valid)[i],
+                         st.terminated[i], st.invalid[i], st.step[i], st.id[i],
+                         __float_as_uint(st.score[i]), __float_as_uint(st.reward[i]), with_id);
+    }
+    block_add_u64(h, out);
+}
+
+// ---- fused rollout -----------------------------------------------------------------------------------
+// One lane keeps one board (and its whole record) in registers for all N steps; per step:
+// prepare (re-deal if terminated) -> sample action (rocRAND Philox) -> move/merge/reward/spawn/mask.
+// Global traffic per step is the 16-byte permutation row(s) (L1/L2-resident 16 KiB table), the
+// optional 1-byte action, and 8 bytes of re-deal flags per wave; state is read once and written
+// once per launch.
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, int64_t idx_base, int N,
+                                                    const uint8_t *__restrict__ perm_epochs,
+                                                    const uint32_t *__restrict__ two_masks,
+                                                    const int32_t *__restrict__ schedule, int masked,
+                                                    uint64_t act_seed, uint64_t act_counter0,
+                                                    uint8_t *__restrict__ actions_out,
+                                                    uint64_t *__restrict__ digests_out,
+                                                    uint64_t *__restrict__ reset_flags, int64_t flag_words,
+                                                    int32_t *__restrict__ last_reset) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < M;
+    const int64_t ii = live ? i : M - 1; // tail lanes shadow the last board (loads only, no stores)
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_global = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+
+    StepRegs s;
+    s.board = load_board(st.board, ii);
+    {
+        const uint4 m = reinterpret_cast<const uint4 *>(st.merged)[ii];
+        s.merged[0] = m.x; s.merged[1] = m.y; s.merged[2] = m.z; s.merged[3] = m.w;
+    }
+    s.valid = reinterpret_cast<const uint32_t *>(st.valid)[ii];
+    s.step = st.step[ii];
+    s.score = st.score[ii];
+    s.reward = st.reward[ii];
+    s.terminated = st.terminated[ii];
+    uint32_t invalid = st.invalid[ii];
+    Board prev_board = load_board(st.prev_board, ii);
+    uint32_t prev_valid = reinterpret_cast<const uint32_t *>(st.prev_valid)[ii];
+    int32_t last = -1;
+
+    for (int t = 0; t < N; ++t) {
+        const int epoch = schedule[3 * t + 0];
+        const int64_t row_p = schedule[3 * t + 1];
+        const int64_t row_s = schedule[3 * t + 2];
+        const uint8_t *table = perm_epochs + (int64_t)epoch * (ML2048_RAND_SIZE * 16);
+        const uint32_t two_mask = two_masks[epoch];
+
+        // ---- prepare (game_numba.py:619-658)
+        const bool deal = s.terminated != 0;
+        const unsigned long long dealt = __ballot(deal && live);
+        if (lane == 0) reset_flags[(int64_t)t * flag_words + wave_global] = dealt;
+        if (deal) {
+            clear_regs(s);
+            invalid = 0;
+            uint32_t perm[4];
+            load_perm_row(table, row_p + idx_base + ii, perm);
+            spawn_table(s.board, perm, two_mask, 2);
+            s.valid = valid_actions(s.board);
+            last = t;
+        }
+        // ---- sample (policy/random.py:17-27)
+        const uint32_t word = rocrand_word0(act_seed, act_counter0 + (uint64_t)t, (uint64_t)(idx_base + ii));
+        uint32_t cnt;
+        const uint32_t action = pick_action(masked ? s.valid : 0x01010101u, word, masked, cnt);
+        if (actions_out && live) actions_out[(int64_t)t * M + i] = (uint8_t)action;
+        // ---- step (game_numba.py:660-738)
+        prev_board = s.board;
+        prev_valid = s.valid;
+        if (step_pre(s, action, KIND)) {
+            uint32_t perm[4];
+            load_perm_row(table, row_s + idx_base + ii, perm);
+            spawn_table(s.board, perm, two_mask, 1);
+            step_post(s);
+            invalid = 0;
+        } else {
+            invalid = 1;
+        }
+        if (digests_out) {
+            uint64_t h = 0;
+            if (live)
+                h = board_digest((uint64_t)(idx_base + i), s.board, s.merged, s.valid, s.terminated, invalid,
+                                 s.step, 0, __float_as_uint(s.score), __float_as_uint(s.reward), 0);
+            h = wave_sum_u64(h);
+            if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(digests_out + t), (unsigned long long)h);
+        }
+    }
+
+    if (!live) return;
+    store16(st.board, i, s.board.r);
+    store16(st.merged, i, s.merged);
+    store16(st.prev_board, i, prev_board.r);
+    reinterpret_cast<uint32_t *>(st.valid)[i] = s.valid;
+    reinterpret_cast<uint32_t *>(st.prev_valid)[i] = prev_valid;
+    st.step[i] = s.step;
+    st.score[i] = s.score;
+    st.reward[i] = s.reward;
+    st.terminated[i] = (uint8_t)s.terminated;
+    st.invalid[i] = (uint8_t)invalid;
+    last_reset[i] = last;
+}
+
+// ids after a rollout.  scratch: [0, N*W) exclusive prefix of popcounts inside each step's flag
+// row; [N*W, N*W+N] exclusive prefix of per-step totals (last entry = grand total).
+__global__ __launch_bounds__(256) void k_ids_rowscan(const uint64_t *__restrict__ flags, int64_t W, int N,
+                                                     int32_t *__restrict__ scratch) {
+    __shared__ int wave_tot[4];
+    __shared__ int carry_s;
+    const int t = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < W; base += 256) {
+        const int64_t j = base + threadIdx.x;
+        const int v = j < W ? __popcll(flags[(int64_t)t * W + j]) : 0;
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int n = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += n;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int wave_base = 0;
+        for (int w = 0; w < wave; ++w) wave_base += wave_tot[w];
+        const int carry = carry_s;
+        if (j < W) scratch[(int64_t)t * W + j] = carry + wave_base + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = carry + wave_base + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scratch[(int64_t)N * W + t] = carry_s; // per-step total (scanned next)
+}
+
+__global__ __launch_bounds__(64) void k_ids_stepscan(int32_t *__restrict__ tot, int N,
+                                                     int32_t *__restrict__ step_resets) {
+    // single wave, serial over chunks of 64 steps; N is small (hundreds..thousands)
+    const int lane = threadIdx.x;
+    int carry = 0;
+    for (int base = 0; base < N; base += 64) {
+        const int j = base + lane;
+        const int v = j < N ? tot[j] : 0;
+        if (step_resets && j < N) step_resets[j] = v;
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int n = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += n;
+        }
+        if (j < N) tot[j] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) tot[N] = carry;
+}
+
+__global__ __launch_bounds__(kBlock) void k_ids_assign(ml2048_state st, int64_t M, int N, int64_t W,
+                                                       const uint64_t *__restrict__ flags,
+                                                       const int32_t *__restrict__ last_reset,
+                                                       const int32_t *__restrict__ scratch,
+                                                       int32_t *__restrict__ game_count, int32_t gc_snapshot_slot) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int32_t *step_base = scratch + (int64_t)N * W;
+    const int32_t gc0 = scratch[gc_snapshot_slot];
+    if (i == 0) *game_count = gc0 + step_base[N];
+    if (i >= M) return;
+    const int t = last_reset[i];
+    if (t < 0) return;
+    const int64_t w = i >> 6;
+    const unsigned long long f = flags[(int64_t)t * W + w];
+    const int rank = scratch[(int64_t)t * W + w] + __popcll(f & ((1ull << (i & 63)) - 1ull));
+    st.id[i] = gc0 + step_base[t] + rank;
+}
+
+__global__ void k_snapshot(const int32_t *__restrict__ src, int32_t *__restrict__ dst) { *dst = *src; }
+
+uint64_t two_threshold(double two_prob) {
+    double t = two_prob * 4294967296.0;
+    if (!(t > 0.0)) return 0;
+    if (t >= 4294967296.0) return 4294967296ull;
+    uint64_t c = (uint64_t)t;
+    if ((double)c < t) c += 1;
+    return c;
+}
+
+template <bool FAST>
+int launch_step(hipStream_t s, int64_t M, int64_t idx_base, const ml2048_state *st, const void *actions,
+                int action_dtype, int reward_kind, double two_prob, int64_t row_base,
+                const uint8_t *randperm, const float *randfloat, uint64_t seed, uint64_t counter) {
+    const dim3 grid((unsigned)cdiv(M, kBlock)), block(kBlock);
+    const uint64_t thr = two_threshold(two_prob);
+#define ML_LAUNCH(K)                                                                                   \
+    hipLaunchKernelGGL((k_step<K, FAST>), grid, block, 0, s, *st, M, idx_base, actions, action_dtype, \
+                       two_prob, row_base, randperm, randfloat, seed, counter, thr)
+    switch (reward_kind) {
+    case ML2048_REWARD_NORMAL: ML_LAUNCH(REWARD_NORMAL); break;
+    case ML2048_REWARD_IMPROVED: ML_LAUNCH(REWARD_IMPROVED); break;
+    case ML2048_REWARD_RANK: ML_LAUNCH(REWARD_RANK); break;
+    case ML2048_REWARD_MAXCELL: ML_LAUNCH(REWARD_MAXCELL); break;
+    default: return fail(ML2048_E_INVALID, "reward_kind=%d", reward_kind);
+    }
+#undef ML_LAUNCH
+    return check_launch("ml2048_step");
+}
+
+template <bool FAST>
+int launch_prepare(hipStream_t s, int64_t M, int64_t idx_base, const ml2048_state *st,
+                   const uint8_t *randperm, const float *randfloat, double two_prob, int64_t row_base,
+                   uint64_t seed, uint64_t counter, int32_t *game_count, int32_t *n_reset,
+                   int64_t *reset_indices, int32_t *scratch) {
+    if (!game_count || !n_reset || !scratch)
+        return fail(ML2048_E_INVALID, "game_count, n_reset and scratch must be non-NULL");
+    const int nblk = (int)cdiv(M, kPrepBlock);
+    hipLaunchKernelGGL(k_prep_count, dim3(nblk), dim3(kPrepBlock), 0, s, st->terminated, M, scratch);
+    hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, s, scratch, nblk, game_count);
+    hipLaunchKernelGGL((k_prep_deal<FAST>), dim3(nblk), dim3(kPrepBlock), 0, s, *st, M, idx_base, randperm,
+                       randfloat, two_prob, row_base, seed, counter, two_threshold(two_prob), scratch, nblk,
+                       game_count, n_reset, reset_indices);
+    return check_launch("ml2048_prepare");
+}
+
+} // namespace
+
+// ================================================================================================
+extern "C" {
+
+int ml2048_abi_version(void) { return ML2048_ABI_VERSION; }
+
+const char *ml2048_last_error(void) { return g_err; }
+
+int64_t ml2048_scratch_ints(int64_t M) { return M > 0 ? cdiv(M, kPrepBlock) + 2 : 2; }
+
+int ml2048_reset(void *stream, int64_t M, const ml2048_state *st) {
+    if (int rc = check_state(M, st)) return rc;
+    hipLaunchKernelGGL(k_reset, dim3((unsigned)cdiv(M, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, *st, M);
+    return check_launch("ml2048_reset");
+}
+
+int ml2048_prepare(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st,
+                   const uint8_t *randperm, const float *randfloat, double two_prob, int64_t row_base,
+                   int32_t *game_count, int32_t *n_reset, int64_t *reset_indices, int32_t *scratch) {
+    if (int rc = check_state(M, st)) return rc;
+    if (!randperm || !randfloat) return fail(ML2048_E_INVALID, "randperm/randfloat is NULL");
+    if ((uintptr_t)randperm % 16) return fail(ML2048_E_ALIGN, "randperm must be 16-byte aligned");
+    if (row_base < 0 || idx_base < 0) return fail(ML2048_E_INVALID, "row_base/idx_base must be >= 0");
+    return launch_prepare<false>((hipStream_t)stream, M, idx_base, st, randperm, randfloat, two_prob, row_base, 0, 0,
+                                 game_count, n_reset, reset_indices, scratch);
+}
+
+int ml2048_prepare_fast(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, double two_prob,
+                        uint64_t seed, uint64_t counter, int32_t *game_count, int32_t *n_reset,
+                        int64_t *reset_indices, int32_t *scratch) {
+    if (int rc = check_state(M, st)) return rc;
+    if (idx_base < 0) return fail(ML2048_E_INVALID, "idx_base must be >= 0");
+    return launch_prepare<true>((hipStream_t)stream, M, idx_base, st, nullptr, nullptr, two_prob, 0, seed, counter,
+                                game_count, n_reset, reset_indices, scratch);
+}
+
+int ml2048_step(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, const void *actions,
+                int action_dtype, int reward_kind, double two_prob, int64_t row_base,
+                const uint8_t *randperm, const float *randfloat) {
+    if (int rc = check_state(M, st)) return rc;
+    if (!actions || !randperm || !randfloat) return fail(ML2048_E_INVALID, "actions/randperm/randfloat is NULL");
+    if ((uintptr_t)randperm % 16) return fail(ML2048_E_ALIGN, "randperm must be 16-byte aligned");
+    if (action_dtype < 0 || action_dtype > 2) return fail(ML2048_E_INVALID, "action_dtype=%d", action_dtype);
+    if (row_base < 0 || idx_base < 0) return fail(ML2048_E_INVALID, "row_base/idx_base must be >= 0");
+    return launch_step<false>((hipStream_t)stream, M, idx_base, st, actions, action_dtype, reward_kind, two_prob,
+                              row_base, randperm, randfloat, 0, 0);
+}
+
+int ml2048_step_fast(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, const void *actions,
+                     int action_dtype, int reward_kind, double two_prob, uint64_t seed, uint64_t counter) {
+    if (int rc = check_state(M, st)) return rc;
+    if (!actions) return fail(ML2048_E_INVALID, "actions is NULL");
+    if (action_dtype < 0 || action_dtype > 2) return fail(ML2048_E_INVALID, "action_dtype=%d", action_dtype);
+    if (idx_base < 0) return fail(ML2048_E_INVALID, "idx_base must be >= 0");
+    return launch_step<true>((hipStream_t)stream, M, idx_base, st, actions, action_dtype, reward_kind, two_prob, 0,
+                             nullptr, nullptr, seed, counter);
+}
+
+int ml2048_sample_actions(void *stream, int64_t M, int64_t idx_base, const uint8_t *valid, uint64_t seed,
+                          uint64_t counter, int masked, uint8_t *actions, float *logp) {
+    if (M <= 0) return fail(ML2048_E_INVALID, "M=%lld must be positive", (long long)M);
+    if (!actions || (masked && !valid)) return fail(ML2048_E_INVALID, "actions/valid is NULL");
+    if (masked && (uintptr_t)valid % 4) return fail(ML2048_E_ALIGN, "valid must be 4-byte aligned");
+    hipLaunchKernelGGL(k_sample, dim3((unsigned)cdiv(M, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, valid, M,
+                       idx_base, seed, counter, masked, actions, logp);
+    return check_launch("ml2048_sample_actions");
+}
+
+int ml2048_encode_onehot(void *stream, int64_t M, const uint8_t *board, float *onehot, int64_t *board_i64,
+                         int32_t *bad_count) {
+    if (M <= 0) return fail(ML2048_E_INVALID, "M=%lld must be positive", (long long)M);
+    if (!board || !onehot) return fail(ML2048_E_INVALID, "board/onehot is NULL");
+    if ((uintptr_t)board % 16 || (uintptr_t)onehot % 16) return fail(ML2048_E_ALIGN, "board/onehot must be 16-byte aligned");
+    // 64 boards per wave iteration; cap the grid and stride (each wave keeps >= 1 chunk)
+    int64_t waves = cdiv(M, 64);
+    int64_t blocks = cdiv(waves, kBlock / 64);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(k_onehot, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, board, M, onehot,
+                       board_i64, bad_count);
+    return check_launch("ml2048_encode_onehot");
+}
+
+int ml2048_hist_maxcell(void *stream, int64_t M, const uint8_t *board, const uint8_t *terminated, int32_t *counts) {
+    if (M <= 0) return fail(ML2048_E_INVALID, "M=%lld must be positive", (long long)M);
+    if (!board || !counts) return fail(ML2048_E_INVALID, "board/counts is NULL");
+    if ((uintptr_t)board % 16) return fail(ML2048_E_ALIGN, "board must be 16-byte aligned");
+    int64_t blocks = cdiv(M, kBlock);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_hist, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, board, terminated, M, counts);
+    return check_launch("ml2048_hist_maxcell");
+}
+
+int ml2048_pack_records(void *stream, int64_t M, const ml2048_state *st, void *records) {
+    if (int rc = check_state(M, st)) return rc;
+    if (!records || (uintptr_t)records % 16) return fail(ML2048_E_ALIGN, "records must be non-NULL, 16-byte aligned");
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)cdiv(M, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, *st, M, (uint4 *)records);
+    return check_launch("ml2048_pack_records");
+}
+
+int ml2048_unpack_records(void *stream, int64_t M, const ml2048_state *st, const void *records) {
+    if (int rc = check_state(M, st)) return rc;
+    if (!records || (uintptr_t)records % 16) return fail(ML2048_E_ALIGN, "records must be non-NULL, 16-byte aligned");
+    hipLaunchKernelGGL(k_unpack, dim3((unsigned)cdiv(M, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, *st, M, (const uint4 *)records);
+    return check_launch("ml2048_unpack_records");
+}
+
+int ml2048_digest(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int with_id, uint64_t *out) {
+    if (int rc = check_state(M, st)) return rc;
+    if (!out || (uintptr_t)out % 8) return fail(ML2048_E_ALIGN, "out must be non-NULL, 8-byte aligned");
+    hipLaunchKernelGGL(k_digest, dim3((unsigned)cdiv(M, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, *st, M, idx_base, with_id, out);
+    return check_launch("ml2048_digest");
+}
+
+int ml2048_debug_philox(void *stream, int64_t n, int64_t idx_base, uint64_t seed, uint64_t counter, uint32_t *out) {
+    if (n <= 0 || !out || (uintptr_t)out % 16) return fail(ML2048_E_INVALID, "n/out");
+    hipLaunchKernelGGL(k_debug_philox, dim3((unsigned)cdiv(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, n, idx_base, seed, counter, out);
+    return check_launch("ml2048_debug_philox");
+}
+
+int64_t ml2048_rollout_flag_words(int64_t M) { return M > 0 ? cdiv(M, kBlock) * (kBlock / 64) : 0; }
+
+int64_t ml2048_rollout_scratch_ints(int64_t M, int32_t N) {
+    if (M <= 0 || N <= 0) return 0;
+    return (int64_t)N * ml2048_rollout_flag_words(M) + N + 2;
+}
+
+int ml2048_rollout(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
+                   const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,
+                   const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0,
+                   uint8_t *actions_out, uint64_t *digests_out, uint64_t *reset_flags, int32_t *last_reset) {
+    if (int rc = check_state(M, st)) return rc;
+    if (N <= 0 || n_epochs <= 0) return fail(ML2048_E_INVALID, "N=%d n_epochs=%d must be positive", N, n_epochs);
+    if (!perm_epochs || !two_masks || !schedule || !reset_flags || !last_reset)
+        return fail(ML2048_E_INVALID, "perm_epochs/two_masks/schedule/reset_flags/last_reset is NULL");
+    if ((uintptr_t)perm_epochs % 16) return fail(ML2048_E_ALIGN, "perm_epochs must be 16-byte aligned");
+    if (idx_base < 0) return fail(ML2048_E_INVALID, "idx_base must be >= 0");
+    const dim3 grid((unsigned)cdiv(M, kBlock)), block(kBlock);
+    const int64_t W = ml2048_rollout_flag_words(M);
+    hipStream_t s = (hipStream_t)stream;
+#define ML_LAUNCH(K)                                                                                          \
+    hipLaunchKernelGGL((k_rollout<K>), grid, block, 0, s, *st, M, idx_base, N, perm_epochs, two_masks,       \
+                       schedule, masked, act_seed, act_counter0, actions_out, digests_out, reset_flags, W,  \
+                       last_reset)
+    switch (reward_kind) {
+    case ML2048_REWARD_NORMAL: ML_LAUNCH(REWARD_NORMAL); break;
+    case ML2048_REWARD_IMPROVED: ML_LAUNCH(REWARD_IMPROVED); break;
+    case ML2048_REWARD_RANK: ML_LAUNCH(REWARD_RANK); break;
+    case ML2048_REWARD_MAXCELL: ML_LAUNCH(REWARD_MAXCELL); break;
+    default: return fail(ML2048_E_INVALID, "reward_kind=%d", reward_kind);
+    }
+#undef ML_LAUNCH
+    return check_launch("ml2048_rollout");
+}
+
+int ml2048_rollout_finish_ids(void *stream, int64_t M, const ml2048_state *st, int32_t N,
+                              const uint64_t *reset_flags, const int32_t *last_reset, int32_t *game_count,
+                              int32_t *step_resets, int32_t *scratch) {
+    if (int rc = check_state(M, st)) return rc;
+    if (N <= 0 || !reset_flags || !last_reset || !game_count || !scratch)
+        return fail(ML2048_E_INVALID, "N/reset_flags/last_reset/game_count/scratch");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t W = ml2048_rollout_flag_words(M);
+    const int64_t snap = (int64_t)N * W + N + 1;
+    if (snap > 0x7FFFFFFF) return fail(ML2048_E_UNSUPPORTED, "N*M too large for one finish_ids call");
+    hipLaunchKernelGGL(k_snapshot, dim3(1), dim3(1), 0, s, game_count, scratch + snap);
+    hipLaunchKernelGGL(k_ids_rowscan, dim3((unsigned)N), dim3(256), 0, s, reset_flags, W, N, scratch);
+    hipLaunchKernelGGL(k_ids_stepscan, dim3(1), dim3(64), 0, s, scratch + (int64_t)N * W, N, step_resets);
+    hipLaunchKernelGGL(k_ids_assign, dim3((unsigned)cdiv(M, kBlock)), dim3(kBlock), 0, s, *st, M, N, W, reset_flags,
+                       last_reset, scratch, game_count, (int32_t)snap);
+    return check_launch("ml2048_rollout_finish_ids");
+}
+
+} // extern "C"

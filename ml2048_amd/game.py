@@ -1,0 +1,438 @@
+"""`VecGame`: the reference's vectorized 2048 environment API on MI355X HIP kernels.
+
+Drop-in for `ml2048.game_numba.VecGame` (src/ml2048/game_numba.py:522-698): same constructor,
+`reset / prepare / observations / step / summary`, same `VecStepResult` keys and dtypes, same
+private attributes callers read (`_size`, `_data`, `_game_count`, `_rand_step`, ...).  All
+per-board work runs in libml2048_hip.so through the C ABI of include/ml2048_hip.h; state lives in
+HBM as PyTorch-ROCm tensors (caller-visible, structure-of-arrays).  Besides the numpy-returning
+reference API there is a device-native one (`*_torch`, `onehot`, `rollout`) that never leaves the GPU.
+
+Differences from the reference, all deliberate and documented in DESIGN.md:
+  * `reward_fn` is one of the four reference reward functions, passed as the sentinel objects
+    exported here (or their names): a Python callback cannot be fused into a HIP kernel.
+  * the numpy API returns snapshots, not aliasing views of live state (hazard H12).
+  * out-of-range actions are treated as invalid moves instead of undefined behaviour (H11).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Optional, TypedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from .hostrng import RAND_SIZE, HostRng
+
+# src/ml2048/game.py:14-17
+STEP_LEFT = 0
+STEP_RIGHT = 1
+STEP_UP = 2
+STEP_DOWN = 3
+
+# game_numba.py:23-45
+ITEM_VALUES = np.array([0] + [2**k for k in range(1, 18)], dtype=np.int32)
+
+# game_numba.py:537-551
+RECORD_DTYPE = np.dtype(
+    [
+        ("id", np.int32, ()),
+        ("step", np.int32, ()),
+        ("score", np.float32, ()),
+        ("reward", np.float32, ()),
+        ("board", np.uint8, (16,)),
+        ("merged", np.uint8, (16,)),
+        ("valid_actions", np.uint8, (4,)),
+        ("terminated", np.uint8, ()),
+        ("invalid", np.uint8, ()),
+        ("_padding", np.uint8, 10),
+    ],
+    align=True,
+)
+assert RECORD_DTYPE.itemsize == 64, RECORD_DTYPE.itemsize
+
+
+class RewardFn:
+    """Sentinel for one of the reference's reward functions (game_numba.py:408-504).
+
+    Pass it as `VecGame(reward_fn=...)`; the kernel computes it on device.  Calling it evaluates
+    the same formula on one (state, prev_state, merged) triple on the host (convenience only).
+    """
+
+    def __init__(self, name: str, kind: int):
+        self.name, self.kind = name, kind
+        self.__name__ = f"reward_fn_{name}"
+
+    def __repr__(self) -> str:
+        return f"<ml2048_amd.{self.__name__}>"
+
+    def __call__(self, state, prev_state, merged) -> float:
+        state = [int(v) for v in state]
+        prev_state = [int(v) for v in prev_state]
+        merged = [int(v) for v in merged][:16]
+        normal = sum(m * (2 << k) for k, m in enumerate(merged))
+        if self.kind == 0:
+            return float(normal)
+        if self.kind == 1:
+            extra = 0
+            if prev_state[0] != 0:
+                extra -= 64 * (1 << prev_state[0])
+            if state[0] != 0:
+                extra += 64 * (1 << state[0])
+            return float(normal) + float(extra)
+        if self.kind == 2:
+            return float(sum((k + 1) * m for k, m in enumerate(merged)))
+        reward = 0.0
+        if max(state) > max(prev_state):
+            reward += float(2 ** max(state))
+        return reward + float(sum(merged))
+
+
+reward_fn_normal = RewardFn("normal", 0)
+reward_fn_improved = RewardFn("improved", 1)
+reward_fn_rank = RewardFn("rank", 2)
+reward_fn_maxcell = RewardFn("maxcell", 3)
+_REWARDS = {r.name: r for r in (reward_fn_normal, reward_fn_improved, reward_fn_rank, reward_fn_maxcell)}
+
+
+def _reward_kind(reward_fn) -> int:
+    if reward_fn is None:
+        return 0
+    if isinstance(reward_fn, RewardFn):
+        return reward_fn.kind
+    if isinstance(reward_fn, str) and reward_fn in _REWARDS:
+        return _REWARDS[reward_fn].kind
+    if isinstance(reward_fn, int) and 0 <= reward_fn < 4:
+        return reward_fn
+    name = getattr(reward_fn, "__name__", "")
+    if name.startswith("reward_fn_") and name[len("reward_fn_"):] in _REWARDS:
+        return _REWARDS[name[len("reward_fn_"):]].kind  # the reference's own function objects
+    raise TypeError(
+        "reward_fn must be one of ml2048_amd.reward_fn_{normal,improved,rank,maxcell} (or its name): "
+        "an arbitrary Python callable cannot be compiled into the HIP step kernel"
+    )
+
+
+class VecStepResult(TypedDict):  # game_numba.py:507-519
+    state: Any
+    valid_actions: Any
+    step: Any
+    merged: Any
+    reward: Any
+    score: Any
+    terminated: Any
+    invalid: Any
+    prev_state: Any
+    prev_valid_actions: Any
+
+
+_ACT_CODE = {torch.uint8: 0, torch.int32: 1, torch.int64: 2}
+
+
+class VecGame:
+    """Vectorized 2048 environment on one MI355X (see module docstring)."""
+
+    _RAND_SIZE: int = RAND_SIZE
+    _DATA_DTYPE = RECORD_DTYPE
+
+    def __init__(
+        self,
+        size: int,
+        reward_fn=None,
+        *,
+        two_prob: float = 0.8,
+        reuse_state: bool = False,
+        device: torch.device | str | None = None,
+        spawn: str = "table",
+        spawn_seed: Optional[int] = None,
+        idx_base: int = 0,
+    ):
+        if size <= 0:
+            raise ValueError(f"size={size}")  # game_numba.py:561-562
+        if spawn not in ("table", "rocrand"):
+            raise ValueError(f"spawn={spawn!r} (expected 'table' or 'rocrand')")
+        self._L = _lib.load()  # raises when the HIP extension is missing: no fallback
+        if not torch.cuda.is_available():
+            raise _lib.Ml2048Error("ml2048_amd needs a ROCm GPU (no CPU fallback)")
+        self.device = torch.device(device if device is not None else "cuda:0")
+        if self.device.type != "cuda":
+            raise ValueError(f"device={self.device}: VecGame state lives in GPU memory")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+
+        self._size = int(size)
+        self._two_prob = float(two_prob)
+        self._reuse_state = reuse_state  # stored, never read - as in the reference (:569)
+        self._reward_fn = reward_fn if reward_fn is not None else reward_fn_normal
+        self._reward_kind = _reward_kind(reward_fn)
+        self._spawn = spawn
+        self._spawn_seed = 0x2048 if spawn_seed is None else int(spawn_seed)
+        self._idx_base = int(idx_base)
+
+        M, dev = self._size, self.device
+        u8, i32, f32 = torch.uint8, torch.int32, torch.float32
+        self.board = torch.empty((M, 16), dtype=u8, device=dev)
+        self.merged = torch.empty((M, 16), dtype=u8, device=dev)
+        self.valid_actions = torch.empty((M, 4), dtype=u8, device=dev)
+        self.step_count = torch.empty((M,), dtype=i32, device=dev)
+        self.score = torch.empty((M,), dtype=f32, device=dev)
+        self.reward = torch.empty((M,), dtype=f32, device=dev)
+        self.terminated = torch.empty((M,), dtype=u8, device=dev)
+        self.invalid = torch.empty((M,), dtype=u8, device=dev)
+        self.game_id = torch.empty((M,), dtype=i32, device=dev)
+        self.prev_state = torch.empty((M, 16), dtype=u8, device=dev)
+        self.prev_valid_actions = torch.empty((M, 4), dtype=u8, device=dev)
+        self._state = _lib.State(
+            self.board.data_ptr(), self.merged.data_ptr(), self.valid_actions.data_ptr(),
+            self.step_count.data_ptr(), self.score.data_ptr(), self.reward.data_ptr(),
+            self.terminated.data_ptr(), self.invalid.data_ptr(), self.game_id.data_ptr(),
+            self.prev_state.data_ptr(), self.prev_valid_actions.data_ptr(),
+        )
+        self._randperm_dev = torch.empty((RAND_SIZE, 16), dtype=u8, device=dev)
+        self._randfloat_dev = torch.empty((RAND_SIZE,), dtype=f32, device=dev)
+        self._game_count_dev = torch.zeros((1,), dtype=i32, device=dev)  # :582 - survives reset()
+        self._n_reset_dev = torch.zeros((1,), dtype=i32, device=dev)
+        self._reset_indices = torch.empty((M,), dtype=torch.int64, device=dev)
+        self._scratch = torch.empty((int(self._L.ml2048_scratch_ints(M)),), dtype=i32, device=dev)
+        self._hist = torch.zeros((20,), dtype=i32, device=dev)
+        self._fast_counter = 0
+        self.reset()  # :584 (unseeded, as the reference constructor does)
+
+    # ------------------------------------------------------------------------------------------
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _st(self):
+        return C.byref(self._state)
+
+    def _upload_tables(self) -> None:
+        self._randperm_dev.copy_(torch.from_numpy(self._rng.randperm))
+        self._randfloat_dev.copy_(torch.from_numpy(self._rng.randfloat))
+
+    # reference-visible private attributes
+    @property
+    def _rand_step(self) -> int:
+        return self._rng.rand_step
+
+    @property
+    def _randperm(self) -> np.ndarray:
+        return self._rng.randperm
+
+    @property
+    def _randfloat(self) -> np.ndarray:
+        return self._rng.randfloat
+
+    @property
+    def _game_count(self) -> int:
+        return int(self._game_count_dev.item())
+
+    @property
+    def _prev_state(self) -> np.ndarray:
+        return self.prev_state.cpu().numpy()
+
+    @property
+    def _prev_valid_actions(self) -> np.ndarray:
+        return self.prev_valid_actions.cpu().numpy()
+
+    @property
+    def _data(self) -> np.ndarray:
+        """Snapshot of the game records in the reference's 64-byte layout (`VecGame._data`,
+        game_numba.py:571), e.g. for `game._data[slot]["id"]` (src/ml2048/replay.py:147-151)."""
+        return self.records_torch().cpu().numpy().view(RECORD_DTYPE).reshape(self._size)
+
+    def records_torch(self) -> torch.Tensor:
+        rec = torch.empty((self._size, 64), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.ml2048_pack_records(self._stream(), self._size, self._st(), rec.data_ptr()), "pack_records")
+        return rec
+
+    def load_records(self, records: np.ndarray) -> None:
+        """Overwrite the device state from reference-layout records (tests / restoring a run)."""
+        rec = np.ascontiguousarray(records).view(np.uint8).reshape(self._size, 64)
+        dev = torch.from_numpy(rec).to(self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.ml2048_unpack_records(self._stream(), self._size, self._st(), dev.data_ptr()), "unpack_records")
+
+    # ------------------------------------------------------------------------------------------
+    def reset(self, seed: Optional[int] = None) -> None:
+        """game_numba.py:606-617.  `_game_count` is NOT reset (only the constructor sets it)."""
+        self._rng = HostRng(seed)
+        self._fast_counter = 0
+        self._upload_tables()
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.ml2048_reset(self._stream(), self._size, self._st()), "reset")
+
+    def observations_torch(self) -> tuple[torch.Tensor, torch.Tensor]:
+        """(board (M,16) uint8, valid_actions (M,4) uint8): live device tensors (aliases)."""
+        return self.board, self.valid_actions
+
+    def observations(self) -> tuple[np.ndarray, np.ndarray]:
+        """game_numba.py:586-587, as host snapshots."""
+        return self.board.cpu().numpy(), self.valid_actions.cpu().numpy()
+
+    def prepare_torch(self) -> tuple[torch.Tensor, torch.Tensor]:
+        """prepare() without a host sync: (reset_indices buffer (M,) int64, n_reset (1,) int32);
+        the first n_reset entries of the buffer are the ascending re-dealt slots."""
+        L, M = self._L, self._size
+        with torch.cuda.device(self.device):
+            if self._spawn == "table":
+                regen, row_base = self._rng.draw_prepare()  # :622-626, drawn unconditionally
+                if regen:
+                    self._upload_tables()
+                rc = L.ml2048_prepare(
+                    self._stream(), M, self._idx_base, self._st(), self._randperm_dev.data_ptr(),
+                    self._randfloat_dev.data_ptr(), self._two_prob, row_base, self._game_count_dev.data_ptr(),
+                    self._n_reset_dev.data_ptr(), self._reset_indices.data_ptr(), self._scratch.data_ptr())
+            else:
+                rc = L.ml2048_prepare_fast(
+                    self._stream(), M, self._idx_base, self._st(), self._two_prob, self._spawn_seed,
+                    2 * self._fast_counter, self._game_count_dev.data_ptr(), self._n_reset_dev.data_ptr(),
+                    self._reset_indices.data_ptr(), self._scratch.data_ptr())
+        _lib.check(rc, "prepare")
+        return self._reset_indices, self._n_reset_dev
+
+    def prepare(self) -> tuple[np.ndarray]:
+        """game_numba.py:619-658: re-deal terminated games; returns (ascending indices,)."""
+        idx, n = self.prepare_torch()
+        k = int(n.item())
+        return (idx[:k].cpu().numpy(),)
+
+    def _as_device_actions(self, actions) -> torch.Tensor:
+        if isinstance(actions, np.ndarray):
+            assert actions.shape == (self._size,), actions.shape  # :668
+            if actions.dtype not in (np.uint8, np.int32, np.int64):
+                actions = actions.astype(np.int64)
+            actions = torch.from_numpy(np.ascontiguousarray(actions))
+        assert tuple(actions.shape) == (self._size,), tuple(actions.shape)
+        if actions.dtype not in _ACT_CODE:
+            actions = actions.to(torch.int64)
+        if actions.device != self.device:
+            actions = actions.to(self.device)
+        return actions.contiguous()
+
+    def step_torch(self, actions) -> VecStepResult:
+        """step() on device tensors; the result aliases live state (like the reference's views)."""
+        a = self._as_device_actions(actions)
+        L, M = self._L, self._size
+        with torch.cuda.device(self.device):
+            if self._spawn == "table":
+                row_base = self._rng.draw_step()  # :670
+                rc = L.ml2048_step(self._stream(), M, self._idx_base, self._st(), a.data_ptr(), _ACT_CODE[a.dtype],
+                                   self._reward_kind, self._two_prob, row_base, self._randperm_dev.data_ptr(),
+                                   self._randfloat_dev.data_ptr())
+            else:
+                rc = L.ml2048_step_fast(self._stream(), M, self._idx_base, self._st(), a.data_ptr(),
+                                        _ACT_CODE[a.dtype], self._reward_kind, self._two_prob, self._spawn_seed,
+                                        2 * self._fast_counter + 1)
+                self._fast_counter += 1
+        _lib.check(rc, "step")
+        return {
+            "state": self.board, "valid_actions": self.valid_actions, "merged": self.merged,
+            "step": self.step_count, "reward": self.reward, "score": self.score,
+            "terminated": self.terminated, "invalid": self.invalid,
+            "prev_state": self.prev_state, "prev_valid_actions": self.prev_valid_actions,
+        }
+
+    def step(self, actions) -> VecStepResult:
+        """game_numba.py:660-698, returning host snapshots of the ten result arrays."""
+        res = self.step_torch(actions)
+        return {k: v.cpu().numpy() for k, v in res.items()}  # type: ignore[return-value]
+
+    # ------------------------------------------------------------------------------------------
+    def onehot(self, out: Optional[torch.Tensor] = None, *, with_long: bool = False, check: bool = False):
+        """(M,16,4,4) float32 observation, what `CNNEncoder.forward` builds from the (M,16) long
+        state (src/ml2048/policy/_network.py:91-95,105).  with_long: also the (M,16) int64 tensor.
+        check: raise like F.one_hot would when a tile exponent >= 16 is present (H10)."""
+        M = self._size
+        if out is None:
+            out = torch.empty((M, 16, 4, 4), dtype=torch.float32, device=self.device)
+        assert out.shape == (M, 16, 4, 4) and out.dtype == torch.float32 and out.is_contiguous()
+        long = torch.empty((M, 16), dtype=torch.int64, device=self.device) if with_long else None
+        bad = torch.zeros((1,), dtype=torch.int32, device=self.device) if check else None
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.ml2048_encode_onehot(
+                self._stream(), M, self.board.data_ptr(), out.data_ptr(),
+                long.data_ptr() if long is not None else None, bad.data_ptr() if bad is not None else None), "onehot")
+        if check and int(bad.item()):
+            raise RuntimeError("Class values must be smaller than num_classes.")  # F.one_hot's message
+        return (out, long) if with_long else out
+
+    def histogram(self, terminated_only: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """counts[max tile exponent] over all boards (or the terminated ones) added into `out`."""
+        if out is None:
+            out = torch.zeros((20,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.ml2048_hist_maxcell(
+                self._stream(), self._size, self.board.data_ptr(),
+                self.terminated.data_ptr() if terminated_only else None, out.data_ptr()), "hist")
+        return out
+
+    def summary(self) -> list[Any]:
+        """game_numba.py:593-604."""
+        counts = self.histogram().cpu().numpy()
+        total = int(counts.sum())
+        entries = [(2 ** k, int(c), int(c) / total) for k, c in enumerate(counts) if c]
+        entries.sort(key=lambda s: s[0], reverse=True)
+        return entries
+
+    def digest(self, with_id: bool = True) -> int:
+        out = torch.zeros((1,), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.ml2048_digest(self._stream(), self._size, self._idx_base, self._st(), int(with_id),
+                                             out.data_ptr()), "digest")
+        return int(out.item()) & 0xFFFFFFFFFFFFFFFF
+
+    # ------------------------------------------------------------------------------------------
+    def rollout(self, n_steps: int, *, masked: bool = True, act_seed: int = 0, act_counter: int = 0,
+                record_actions: bool = False, digests: bool = False, finish_ids: bool = True):
+        """N x {prepare; uniform-random actions; step} fused into one kernel launch, bit-exact
+        with the per-step API on the same seeds (table spawn mode only).
+
+        Returns a dict: actions (N,M) uint8 | None, digests (N,) int64 (two's complement of the
+        uint64) | None, step_resets (N,) int32 | None.
+        """
+        if self._spawn != "table":
+            raise ValueError("rollout() is defined for spawn='table'")
+        N, M, dev = int(n_steps), self._size, self.device
+        if N <= 0:
+            raise ValueError(f"n_steps={n_steps}")
+        # pre-draw the host schedule (independent of game state)
+        epochs = [self._rng.randperm.copy()]
+        masks = [self._rng.two_mask(self._two_prob)]
+        sched = np.empty((N, 3), dtype=np.int32)
+        for t in range(N):
+            regen, row_p = self._rng.draw_prepare()
+            if regen:
+                epochs.append(self._rng.randperm.copy())
+                masks.append(self._rng.two_mask(self._two_prob))
+            row_s = self._rng.draw_step()
+            sched[t] = (len(epochs) - 1, row_p, row_s)
+        perm_dev = torch.from_numpy(np.stack(epochs)).to(dev)
+        mask_dev = torch.from_numpy(np.array(masks, dtype=np.uint32).view(np.int32)).to(dev)
+        sched_dev = torch.from_numpy(sched).to(dev)
+        if len(epochs) > 1:
+            self._upload_tables()  # leave the device tables equal to the host's current ones
+
+        L = self._L
+        W = int(L.ml2048_rollout_flag_words(M))
+        flags = torch.empty((N, W), dtype=torch.int64, device=dev)
+        last = torch.empty((M,), dtype=torch.int32, device=dev)
+        actions = torch.empty((N, M), dtype=torch.uint8, device=dev) if record_actions else None
+        dig = torch.zeros((N,), dtype=torch.int64, device=dev) if digests else None
+        with torch.cuda.device(dev):
+            _lib.check(L.ml2048_rollout(
+                self._stream(), M, self._idx_base, self._st(), N, perm_dev.data_ptr(), mask_dev.data_ptr(),
+                len(epochs), sched_dev.data_ptr(), self._reward_kind, int(masked), int(act_seed), int(act_counter),
+                actions.data_ptr() if actions is not None else None, dig.data_ptr() if dig is not None else None,
+                flags.data_ptr(), last.data_ptr()), "rollout")
+            step_resets = None
+            if finish_ids:
+                step_resets = torch.empty((N,), dtype=torch.int32, device=dev)
+                scratch = torch.empty((int(L.ml2048_rollout_scratch_ints(M, N)),), dtype=torch.int32, device=dev)
+                _lib.check(L.ml2048_rollout_finish_ids(
+                    self._stream(), M, self._st(), N, flags.data_ptr(), last.data_ptr(),
+                    self._game_count_dev.data_ptr(), step_resets.data_ptr(), scratch.data_ptr()), "rollout_finish_ids")
+        # every temporary above was allocated on the launch stream, so the caching allocator's
+        # stream-ordered reuse keeps them valid until the kernels have consumed them
+        return {"actions": actions, "digests": dig, "step_resets": step_resets,
+                "reset_flags": flags, "last_reset": last}

@@ -1,0 +1,132 @@
+"""Rollout driver: the reference's `VecRunner` / `RunnerStats` contract
+(src/ml2048/runner.py:28-189, src/ml2048/event.py) with observations, actions and results kept
+on the GPU (the reference crosses host<->device 2+1+7 times per step, runner.py:91-104 and
+run_train3.py:143-149)."""
+from __future__ import annotations
+
+import collections
+from typing import Any, Callable, Sequence
+
+import numpy as np
+import torch
+
+from .game import VecGame, VecStepResult
+from .policy import Policy, RandomPolicy
+
+
+class EventEmitter:  # src/ml2048/event.py:7-38
+    def __init__(self):
+        self.listeners: dict[str, list[Callable[..., Any]]] = collections.defaultdict(list)
+
+    def add_listener(self, name: str, fn: Callable[..., Any], prepend: bool = False) -> None:
+        if prepend:
+            self.listeners[name].insert(0, fn)
+        else:
+            self.listeners[name].append(fn)
+
+    def has_listeners(self, name: str) -> bool:
+        return bool(self.listeners.get(name))
+
+    def emit(self, name: str, args: tuple[Any, ...], kwargs: dict[str, Any] | None = None) -> None:
+        for fn in self.listeners.get(name, ()):  # noqa: B007
+            fn(*args, **(kwargs or {}))
+
+
+class VecRunner:
+    """prepare -> observations -> policy.sample_actions -> step -> emit, runner.py:74-117.
+
+    Events: "prepared"(env, new_indices) and "stepped"(env, result, actions, log_probs), as in the
+    reference (runner.py:35-43, :80-109).  `new_indices` is a numpy array (it costs one 4-byte
+    D2H sync, paid only when a "prepared" listener is registered); `result` holds device tensors.
+    """
+
+    EVENT_PREPARED = "prepared"
+    EVENT_STEPPED = "stepped"
+
+    def __init__(self, env: VecGame, capacity: int = 0, *, sample_device=None, long_state: bool = True):
+        self.env = env
+        self.sample_device = sample_device if sample_device is not None else env.device
+        self._emitter = EventEmitter()
+        self._vec_size = env._size  # runner.py:57
+        self._capacity = capacity
+        self._long_state = long_state
+
+    def add_callback(self, event: str, fn: Callable[..., Any]) -> None:
+        assert event in {self.EVENT_STEPPED, self.EVENT_PREPARED}
+        self._emitter.add_listener(event, fn)
+
+    def step_once(self, policy: Policy) -> VecStepResult:
+        env = self.env
+        if self._emitter.has_listeners(self.EVENT_PREPARED):
+            (new_indices,) = env.prepare()
+            self._emitter.emit(self.EVENT_PREPARED, (env, new_indices))
+        else:
+            env.prepare_torch()
+        board, valid = env.observations_torch()
+        with torch.no_grad():
+            if isinstance(policy, RandomPolicy):
+                actions, log_probs = policy.sample_actions_u8(valid)
+            else:
+                # the reference hands the policy (N,16) long / (N,4) bool (runner.py:91-95)
+                state = board.to(torch.long) if self._long_state else board
+                actions, log_probs = policy.sample_actions(state, valid.to(torch.bool))
+        result = env.step_torch(actions)
+        self._emitter.emit(self.EVENT_STEPPED, (env, result, actions, log_probs))
+        return result
+
+    def step_many(self, policy: Policy, count: int) -> None:
+        for _ in range(count):
+            self.step_once(policy)
+
+
+class RunnerStats:
+    """Max-tile histogram of terminated games (runner.py:139-189), accumulated on device."""
+
+    def __init__(self):
+        self.counts = np.zeros((20,), dtype=np.int32)
+        self.terminated_count = 0
+        self._dev: torch.Tensor | None = None
+        self._term: torch.Tensor | None = None
+
+    def reset(self) -> None:
+        self.counts.fill(0)
+        self.terminated_count = 0
+        if self._dev is not None:
+            self._dev.zero_()
+            self._term.zero_()
+
+    def on_stepped(self, game: VecGame, result, actions, action_log_probs) -> None:
+        if self._dev is None:
+            self._dev = torch.zeros((20,), dtype=torch.int32, device=game.device)
+            self._term = torch.zeros((1,), dtype=torch.int64, device=game.device)
+        game.histogram(terminated_only=True, out=self._dev)  # _update_count, runner.py:120-136
+        self._term += result["terminated"].sum()
+
+    def sync(self) -> None:
+        """Fold the device accumulators into `counts` / `terminated_count` (one small D2H)."""
+        if self._dev is not None:
+            self.counts += self._dev.cpu().numpy()
+            self.terminated_count += int(self._term.item())
+            self._dev.zero_()
+            self._term.zero_()
+
+    def summary(self) -> list[tuple]:
+        self.sync()
+        total = self.counts.sum()
+        entries = []
+        for power in range(16, 0, -1):
+            count = self.counts[power].item()
+            if count == 0:
+                continue
+            entries.append((2**power, count, count / total))
+        return entries
+
+    @classmethod
+    def combine(cls, seq: Sequence["RunnerStats"]) -> "RunnerStats":
+        """Host-side gather over shards / GPUs (no collective needed: 20 ints per shard)."""
+        for s in seq:
+            s.sync()
+        result = cls()
+        result.counts = np.sum([s.counts for s in seq], axis=0)
+        result.terminated_count = sum(s.terminated_count for s in seq)
+        return result

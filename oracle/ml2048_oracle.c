@@ -317,6 +317,12 @@ static inline void philox_at(uint64_t seed, uint64_t counter, uint64_t idx, uint
     orc_philox4x32_10(ctr, key, out);
 }
 
+/* -ln(cnt) as float32 literals, shared with the HIP kernels so both sides agree bit for bit */
+static inline float neg_log_count(int cnt) {
+    return cnt == 4 ? -1.38629436111989f : cnt == 3 ? -1.09861228866811f
+         : cnt == 2 ? -0.693147180559945f : 0.0f;
+}
+
 void orc_sample_actions(const uint8_t *valid, int64_t valid_stride, int64_t M, int64_t idx_base,
                         uint64_t seed, uint64_t counter, int masked, uint8_t *actions,
                         float *logp) {
@@ -326,7 +332,7 @@ void orc_sample_actions(const uint8_t *valid, int64_t valid_stride, int64_t M, i
         philox_at(seed, counter, (uint64_t)(idx_base + i), r);
         if (!masked) {
             actions[i] = (uint8_t)(r[0] & 3u);
-            if (logp) logp[i] = -logf(4.0f);
+            if (logp) logp[i] = neg_log_count(4);
             continue;
         }
         const uint8_t *v = valid + i * valid_stride;
@@ -347,7 +353,7 @@ void orc_sample_actions(const uint8_t *valid, int64_t valid_stride, int64_t M, i
                 --k;
             }
         actions[i] = (uint8_t)a;
-        if (logp) logp[i] = -logf((float)cnt);
+        if (logp) logp[i] = neg_log_count(cnt);
     }
 }
 
@@ -357,7 +363,7 @@ static inline uint64_t mix_word(uint64_t h, uint64_t w) {
     return h;
 }
 
-uint64_t orc_digest(const orc_record *data, int64_t M, int64_t idx_base) {
+uint64_t orc_digest(const orc_record *data, int64_t M, int64_t idx_base, int with_id) {
     uint64_t total = 0;
 #pragma omp parallel for schedule(static) reduction(+ : total)
     for (int64_t i = 0; i < M; ++i) {
@@ -370,13 +376,14 @@ uint64_t orc_digest(const orc_record *data, int64_t M, int64_t idx_base) {
         uint32_t v;
         memcpy(&v, e->valid_actions, 4);
         w[4] = (uint64_t)v | ((uint64_t)e->terminated << 32) | ((uint64_t)e->invalid << 40);
-        w[5] = (uint64_t)(uint32_t)e->step | ((uint64_t)(uint32_t)e->id << 32);
+        w[5] = (uint64_t)(uint32_t)e->step;
         uint32_t sb, rb;
         memcpy(&sb, &e->score, 4);
         memcpy(&rb, &e->reward, 4);
         w[6] = (uint64_t)sb | ((uint64_t)rb << 32);
         uint64_t h = 0x9E3779B97F4A7C15ull * (uint64_t)(idx_base + i + 1);
         for (int k = 0; k < 7; ++k) h = mix_word(h, w[k]);
+        if (with_id) h = mix_word(h, (uint64_t)(uint32_t)e->id);
         total += h;
     }
     return total;

@@ -108,8 +108,8 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 void orc_sample_actions(const uint8_t *valid, int64_t valid_stride, int64_t M, int64_t idx_base,
                         uint64_t seed, uint64_t counter, int masked, uint8_t *actions, float *logp);
 
-/* order-independent 64-bit digest over all fields of all records + prev buffers */
-uint64_t orc_digest(const orc_record *data, int64_t M, int64_t idx_base);
+/* order-independent 64-bit digest over all record fields of all boards (with_id=0: all but id) */
+uint64_t orc_digest(const orc_record *data, int64_t M, int64_t idx_base, int with_id);
 
 /* Fast-mode spawn (not reference-exact; statistically equivalent): uses philox word pair. */
 void orc_step_fast(orc_record *data, int64_t M, int64_t idx_base, const void *actions,

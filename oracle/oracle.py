@@ -90,7 +90,7 @@ def _bind(L: C.CDLL) -> C.CDLL:
     L.orc_hist_maxcell.argtypes = [vp, i64, vp, i64, i64, vp]
     L.orc_philox4x32_10.argtypes = [vp, vp, vp]
     L.orc_sample_actions.argtypes = [vp, i64, i64, i64, u64, u64, i32, vp, vp]
-    L.orc_digest.argtypes = [vp, i64, i64]
+    L.orc_digest.argtypes = [vp, i64, i64, i32]
     L.orc_digest.restype = u64
     L.orc_step_fast.argtypes = [vp, i64, i64, vp, i32, vp, vp, i32, dbl, u64, u64]
     L.orc_prepare_fast.argtypes = [vp, i64, i64, dbl, u64, u64, vp, vp]
@@ -308,5 +308,5 @@ class OracleVecGame:
         entries.sort(key=lambda s: s[0], reverse=True)
         return entries
 
-    def digest(self) -> int:
-        return int(lib().orc_digest(_p(self._data), self._size, self._idx_base))
+    def digest(self, with_id: bool = True) -> int:
+        return int(lib().orc_digest(_p(self._data), self._size, self._idx_base, int(with_id)))

@@ -1,0 +1,222 @@
+// host_ops_harness.cpp - TEST HARNESS: compiles ml2048_amd/csrc/board_ops.hpp (the device
+// arithmetic) with g++ so the bit tricks can be checked exhaustively on the CPU, without a GPU.
+// Not part of the product; built and loaded only by tests/test_host_ops.py.
+#include <stdint.h>
+#include <string.h>
+
+#include "../../ml2048_amd/csrc/board_ops.hpp"
+
+using namespace ml2048;
+
+extern "C" {
+
+// every 18^4 line (itertools.product order) through push_line; mexp[n][2] = merge exponents
+void h_lines18(uint8_t *result, uint8_t *mexp) {
+    int64_t i = 0;
+    for (uint32_t a = 0; a < 18; ++a)
+        for (uint32_t b = 0; b < 18; ++b)
+            for (uint32_t c = 0; c < 18; ++c)
+                for (uint32_t d = 0; d < 18; ++d, ++i) {
+                    uint32_t x = a | (b << 8) | (c << 16) | (d << 24), m;
+                    uint32_t r = push_line(x, m);
+                    memcpy(result + 4 * i, &r, 4);
+                    mexp[2 * i] = (uint8_t)(m & 0xFF);
+                    mexp[2 * i + 1] = (uint8_t)(m >> 8);
+                }
+}
+
+void h_move(const uint8_t *boards, int64_t n, const uint8_t *actions, uint8_t *out, uint8_t *merged,
+            uint32_t *stats /* n x 3 */) {
+    for (int64_t i = 0; i < n; ++i) {
+        Board b;
+        memcpy(b.r, boards + 16 * i, 16);
+        MoveResult mv = move_board(b, actions[i]);
+        MergeStats st = merge_stats(mv.mexp_first, mv.mexp_second);
+        memcpy(out + 16 * i, mv.board.r, 16);
+        memcpy(merged + 16 * i, st.merged, 16);
+        stats[3 * i] = st.sum_value;
+        stats[3 * i + 1] = st.sum_rank;
+        stats[3 * i + 2] = st.count;
+    }
+}
+
+void h_valid(const uint8_t *boards, int64_t n, uint8_t *valid, uint16_t *empties, uint8_t *maxcell) {
+    for (int64_t i = 0; i < n; ++i) {
+        Board b;
+        memcpy(b.r, boards + 16 * i, 16);
+        uint32_t v = valid_actions(b);
+        memcpy(valid + 4 * i, &v, 4);
+        empties[i] = (uint16_t)empty_mask(b);
+        maxcell[i] = (uint8_t)max_cell(b);
+    }
+}
+
+void h_transpose(const uint8_t *in, uint8_t *out) {
+    Board b;
+    memcpy(b.r, in, 16);
+    Board t = transpose(b);
+    memcpy(out, t.r, 16);
+}
+
+static uint32_t two_mask_of(const float *randfloat, double two_prob) {
+    uint32_t m = 0;
+    for (int c = 0; c < 16; ++c) m |= ((double)randfloat[c] < two_prob ? 1u : 0u) << c;
+    return m;
+}
+
+// records: reference 64-byte layout (id, step, score, reward, board, merged, valid, term, invalid)
+struct Rec {
+    int32_t id, step;
+    float score, reward;
+    uint8_t board[16], merged[16], valid[4], terminated, invalid, pad[10];
+};
+
+static void load(const Rec &e, StepRegs &s) {
+    memcpy(s.board.r, e.board, 16);
+    memcpy(&s.valid, e.valid, 4);
+    memcpy(s.merged, e.merged, 16);
+    s.step = e.step;
+    s.score = e.score;
+    s.reward = e.reward;
+    s.terminated = e.terminated;
+}
+
+static void store(Rec &e, const StepRegs &s) {
+    memcpy(e.board, s.board.r, 16);
+    memcpy(e.valid, &s.valid, 4);
+    memcpy(e.merged, s.merged, 16);
+    e.step = s.step;
+    e.score = s.score;
+    e.reward = s.reward;
+    e.terminated = (uint8_t)s.terminated;
+}
+
+void h_step(Rec *data, int64_t M, int64_t idx_base, const uint8_t *actions, uint8_t *prev_state,
+            uint8_t *prev_valid, int reward_kind, double two_prob, int64_t rand_seed,
+            const uint8_t *randperm, const float *randfloat) {
+    uint32_t two_mask = two_mask_of(randfloat, two_prob);
+    for (int64_t i = 0; i < M; ++i) {
+        Rec &e = data[i];
+        memcpy(prev_state + 16 * i, e.board, 16);
+        memcpy(prev_valid + 4 * i, e.valid, 4);
+        StepRegs s;
+        load(e, s);
+        if (!step_pre(s, actions[i], reward_kind)) {
+            e.invalid = 1;
+            continue;
+        }
+        uint32_t perm[4];
+        memcpy(perm, randperm + 16 * ((rand_seed + idx_base + i) & 1023), 16);
+        spawn_table(s.board, perm, two_mask, 1);
+        step_post(s);
+        store(e, s);
+        e.invalid = 0;
+    }
+}
+
+int64_t h_prepare(Rec *data, int64_t M, int64_t idx_base, int64_t row_base, const uint8_t *randperm,
+                  const float *randfloat, double two_prob, int64_t *game_count) {
+    uint32_t two_mask = two_mask_of(randfloat, two_prob);
+    int64_t n = 0;
+    for (int64_t i = 0; i < M; ++i) {
+        Rec &e = data[i];
+        if (!e.terminated) continue;
+        StepRegs s;
+        clear_regs(s);
+        uint32_t perm[4];
+        memcpy(perm, randperm + 16 * ((row_base + idx_base + i) & 1023), 16);
+        spawn_table(s.board, perm, two_mask, 2);
+        s.valid = valid_actions(s.board);
+        memset(&e, 0, sizeof(e));
+        store(e, s);
+        e.id = (int32_t)(*game_count)++;
+        ++n;
+    }
+    return n;
+}
+
+static uint64_t thr_of(double two_prob) {
+    double t = two_prob * 4294967296.0;
+    double c = (double)(uint64_t)t;
+    if (c < t) c += 1.0;
+    if (c <= 0.0) return 0;
+    if (c >= 4294967296.0) return 4294967296ull;
+    return (uint64_t)c;
+}
+
+void h_step_fast(Rec *data, int64_t M, int64_t idx_base, const uint8_t *actions, uint8_t *prev_state,
+                 uint8_t *prev_valid, int reward_kind, double two_prob, uint64_t seed, uint64_t counter) {
+    uint64_t thr = thr_of(two_prob);
+    for (int64_t i = 0; i < M; ++i) {
+        Rec &e = data[i];
+        memcpy(prev_state + 16 * i, e.board, 16);
+        memcpy(prev_valid + 4 * i, e.valid, 4);
+        StepRegs s;
+        load(e, s);
+        if (!step_pre(s, actions[i], reward_kind)) {
+            e.invalid = 1;
+            continue;
+        }
+        U4 r = philox_at(seed, counter, (uint64_t)(idx_base + i));
+        spawn_counter(s.board, r.x, r.y, thr);
+        step_post(s);
+        store(e, s);
+        e.invalid = 0;
+    }
+}
+
+int64_t h_prepare_fast(Rec *data, int64_t M, int64_t idx_base, double two_prob, uint64_t seed,
+                       uint64_t counter, int64_t *game_count) {
+    uint64_t thr = thr_of(two_prob);
+    int64_t n = 0;
+    for (int64_t i = 0; i < M; ++i) {
+        Rec &e = data[i];
+        if (!e.terminated) continue;
+        StepRegs s;
+        clear_regs(s);
+        U4 r = philox_at(seed, counter, (uint64_t)(idx_base + i));
+        spawn_counter(s.board, r.x, r.y, thr);
+        spawn_counter(s.board, r.z, r.w, thr);
+        s.valid = valid_actions(s.board);
+        memset(&e, 0, sizeof(e));
+        store(e, s);
+        e.id = (int32_t)(*game_count)++;
+        ++n;
+    }
+    return n;
+}
+
+void h_sample(const uint8_t *valid, int64_t M, int64_t idx_base, uint64_t seed, uint64_t counter,
+              int masked, uint8_t *actions, float *logp) {
+    for (int64_t i = 0; i < M; ++i) {
+        uint32_t v;
+        memcpy(&v, valid + 4 * i, 4);
+        U4 r = philox_at(seed, counter, (uint64_t)(idx_base + i));
+        uint32_t cnt;
+        actions[i] = (uint8_t)pick_action(v, r.x, masked, cnt);
+        logp[i] = neg_log_count(cnt);
+    }
+}
+
+uint64_t h_digest(const Rec *data, int64_t M, int64_t idx_base, int with_id) {
+    uint64_t total = 0;
+    for (int64_t i = 0; i < M; ++i) {
+        const Rec &e = data[i];
+        Board b;
+        uint32_t merged[4], valid, sb, rb;
+        memcpy(b.r, e.board, 16);
+        memcpy(merged, e.merged, 16);
+        memcpy(&valid, e.valid, 4);
+        memcpy(&sb, &e.score, 4);
+        memcpy(&rb, &e.reward, 4);
+        total += board_digest((uint64_t)(idx_base + i), b, merged, valid, e.terminated, e.invalid, e.step, e.id, sb, rb, with_id);
+    }
+    return total;
+}
+
+void h_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out) {
+    U4 c = {ctr[0], ctr[1], ctr[2], ctr[3]};
+    U4 r = philox4x32_10(c, key[0], key[1]);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+}

@@ -1,0 +1,238 @@
+"""CPU check of the DEVICE arithmetic: ml2048_amd/csrc/board_ops.hpp compiled with g++ through
+tests/csrc/host_ops_harness.cpp and compared with the golden vectors and the oracle.
+
+This is a test harness for the bit-parallel board code that the HIP kernels inline; it is not a
+product path (the product has no CPU implementation and fails loudly without the HIP library).
+"""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "host_ops_harness.cpp")
+LIB = os.path.join(HERE, "csrc", "libhost_ops_harness.so")
+HDR = os.path.join(HERE, "..", "ml2048_amd", "csrc", "board_ops.hpp")
+
+
+@pytest.fixture(scope="module")
+def H():
+    if not os.path.exists(LIB) or max(os.path.getmtime(SRC), os.path.getmtime(HDR)) > os.path.getmtime(LIB):
+        subprocess.check_call(
+            ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unknown-pragmas", "-o", LIB, SRC]
+        )
+    L = C.CDLL(LIB)
+    vp, i64, i32, u64, dbl = C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_double
+    L.h_lines18.argtypes = [vp, vp]
+    L.h_move.argtypes = [vp, i64, vp, vp, vp, vp]
+    L.h_valid.argtypes = [vp, i64, vp, vp, vp]
+    L.h_transpose.argtypes = [vp, vp]
+    L.h_step.argtypes = [vp, i64, i64, vp, vp, vp, i32, dbl, i64, vp, vp]
+    L.h_prepare.argtypes = [vp, i64, i64, i64, vp, vp, dbl, vp]
+    L.h_prepare.restype = i64
+    L.h_step_fast.argtypes = [vp, i64, i64, vp, vp, vp, i32, dbl, u64, u64]
+    L.h_prepare_fast.argtypes = [vp, i64, i64, dbl, u64, u64, vp]
+    L.h_prepare_fast.restype = i64
+    L.h_sample.argtypes = [vp, i64, i64, u64, u64, i32, vp, vp]
+    L.h_digest.argtypes = [vp, i64, i64, i32]
+    L.h_digest.restype = u64
+    L.h_philox.argtypes = [vp, vp, vp]
+    return L
+
+
+def _p(a):
+    return a.ctypes.data
+
+
+def test_push_line_exhaustive(H, golden_dir):
+    g = np.load(os.path.join(golden_dir, "lines18.npz"))
+    n = 18**4
+    result = np.zeros((n, 4), np.uint8)
+    mexp = np.zeros((n, 2), np.uint8)
+    H.h_lines18(_p(result), _p(mexp))
+    assert np.array_equal(result, g["result"])
+    # merge exponents -> 18-slot bucket array as the reference fills it
+    buckets = np.zeros((n, 18), np.uint8)
+    for j in range(2):
+        m = mexp[:, j]
+        rows = np.flatnonzero(m)
+        np.add.at(buckets, (rows, m[rows]), 1)
+    assert np.array_equal(buckets, g["buckets"])
+    # forward-movable <=> push changes the line; tested through valid_actions below
+
+
+def _random_boards(rng, n, hi=18):
+    b = rng.integers(0, hi, size=(n, 16)).astype(np.uint8)
+    # sprinkle many zeros and equal neighbours
+    mask = rng.random((n, 16)) < 0.35
+    b[mask] = 0
+    dup = rng.random((n, 16)) < 0.3
+    b[:, 1:][dup[:, 1:]] = b[:, :-1][dup[:, 1:]]
+    return b
+
+
+def test_transpose(H):
+    a = np.arange(16, dtype=np.uint8)
+    out = np.zeros(16, np.uint8)
+    H.h_transpose(_p(a), _p(out))
+    assert np.array_equal(out.reshape(4, 4), a.reshape(4, 4).T)
+
+
+def test_move_and_stats_vs_oracle(H, oracle):
+    rng = np.random.default_rng(5)
+    n = 20000
+    boards = _random_boards(rng, n)
+    actions = rng.integers(0, 4, size=n).astype(np.uint8)
+    out = np.zeros((n, 16), np.uint8)
+    merged = np.zeros((n, 16), np.uint8)
+    stats = np.zeros((n, 3), np.uint32)
+    H.h_move(_p(boards), n, _p(actions), _p(out), _p(merged), _p(stats))
+    for i in range(n):
+        ob, om = oracle.step_board(boards[i], int(actions[i]))
+        assert np.array_equal(ob, out[i]), i
+        assert np.array_equal(om[:16], merged[i]), i  # buckets 16/17 dropped (H9)
+        assert oracle.reward("normal", ob, boards[i], om[:16]) == float(stats[i, 0])
+        assert oracle.reward("rank", ob, boards[i], om[:16]) == float(stats[i, 1])
+        assert int(om[:16].sum()) == int(stats[i, 2])
+
+
+def test_valid_empties_maxcell_vs_oracle(H, oracle):
+    rng = np.random.default_rng(6)
+    n = 20000
+    boards = np.concatenate([_random_boards(rng, n - 3), np.zeros((1, 16), np.uint8),
+                             np.full((1, 16), 17, np.uint8),
+                             (np.arange(16, dtype=np.uint8) % 2 + 1).reshape(1, 16)])
+    valid = np.zeros((n, 4), np.uint8)
+    empties = np.zeros(n, np.uint16)
+    maxcell = np.zeros(n, np.uint8)
+    H.h_valid(_p(boards), n, _p(valid), _p(empties), _p(maxcell))
+    for i in range(n):
+        ov, _ = oracle.compute_valid_actions(boards[i])
+        assert np.array_equal(ov, valid[i]), (i, boards[i])
+    exp_empty = ((boards == 0) * (1 << np.arange(16))).sum(axis=1)
+    assert np.array_equal(exp_empty.astype(np.uint16), empties)
+    assert np.array_equal(boards.max(axis=1), maxcell)
+
+
+def _rec(oracle, M):
+    return np.zeros(M, dtype=oracle.RECORD_DTYPE)
+
+
+def _replay_host(H, oracle, g, M, seed, kind):
+    rng = oracle.HostRng(seed)
+    data = _rec(oracle, M)
+    data["terminated"] = 1
+    prev_s = np.zeros((M, 16), np.uint8)
+    prev_v = np.zeros((M, 4), np.uint8)
+    gc = C.c_int64(0)
+    actions = g["actions"]
+    for s in range(actions.shape[0]):
+        _, base_p = rng.draw_prepare()
+        n = H.h_prepare(_p(data), M, 0, base_p, _p(rng.randperm), _p(rng.randfloat), 0.8, C.addressof(gc))
+        assert n == g["n_reset"][s]
+        a = np.ascontiguousarray(actions[s], dtype=np.uint8)
+        base_s = rng.draw_step()
+        H.h_step(_p(data), M, 0, _p(a), _p(prev_s), _p(prev_v), oracle.REWARD_KINDS[kind], 0.8, base_s,
+                 _p(rng.randperm), _p(rng.randfloat))
+        hs = hashlib.sha256(data.tobytes())
+        hs.update(prev_s.tobytes())
+        hs.update(prev_v.tobytes())
+        assert hs.hexdigest() == str(g["step_sha"][s]), f"step {s}"
+    assert gc.value == int(g["game_count"])
+
+
+def test_device_arith_rollout_c1(H, oracle, golden_dir):
+    _replay_host(H, oracle, np.load(os.path.join(golden_dir, "rollout_c1.npz")), 1024, 12345, "normal")
+
+
+def test_device_arith_rollout_long(H, oracle, golden_dir):
+    _replay_host(H, oracle, np.load(os.path.join(golden_dir, "rollout_long.npz")), 256, 1, "normal")
+
+
+@pytest.mark.parametrize("kind", ["normal", "improved", "rank", "maxcell"])
+def test_device_arith_rollout_rewards(H, oracle, golden_dir, kind):
+    g = np.load(os.path.join(golden_dir, "rollout_rewards.npz"))
+    sub = {k[len(kind) + 1:]: g[k] for k in g.files if k.startswith(kind + "_")}
+    _replay_host(H, oracle, sub, 128, 77, kind)
+
+
+def test_high_exponent_merges_match_oracle(H, oracle):
+    """H9: merges of 65536/131072 tiles (bucket index 16/17) - board, reward, merged, mask."""
+    M = 64
+    rng = np.random.default_rng(9)
+    host = oracle.HostRng(3)
+    data = _rec(oracle, M)
+    boards = rng.integers(14, 18, size=(M, 16)).astype(np.uint8)
+    boards[rng.random((M, 16)) < 0.2] = 0
+    for i in range(M):
+        data["board"][i] = boards[i]
+        v, _ = oracle.compute_valid_actions(boards[i])
+        data["valid_actions"][i] = v
+    ref = data.copy()
+    actions = rng.integers(0, 4, size=M).astype(np.uint8)
+    p1, v1 = np.zeros((M, 16), np.uint8), np.zeros((M, 4), np.uint8)
+    p2, v2 = np.zeros((M, 16), np.uint8), np.zeros((M, 4), np.uint8)
+    for kind in range(4):
+        a, b = data.copy(), ref.copy()
+        H.h_step(_p(a), M, 0, _p(actions), _p(p1), _p(v1), kind, 0.8, 17, _p(host.randperm), _p(host.randfloat))
+        oracle.lib().orc_step(_p(b), M, 0, _p(actions), 0, _p(p2), _p(v2), kind, 0.8, 17,
+                              _p(host.randperm), _p(host.randfloat))
+        assert a.tobytes() == b.tobytes(), kind
+
+
+def test_fast_mode_matches_oracle(H, oracle):
+    M, N = 512, 200
+    env = oracle.OracleVecGame(M, "improved", fast_seed=0xC0FFEE)
+    env.reset(0)
+    data = _rec(oracle, M)
+    data["terminated"] = 1
+    prev_s = np.zeros((M, 16), np.uint8)
+    prev_v = np.zeros((M, 4), np.uint8)
+    gc = C.c_int64(0)
+    for s in range(N):
+        (idx,) = env.prepare()
+        n = H.h_prepare_fast(_p(data), M, 0, 0.8, C.c_uint64(0xC0FFEE), C.c_uint64(2 * s), C.addressof(gc))
+        assert n == idx.size
+        a_o, lp_o = oracle.sample_actions(env._data["valid_actions"], 77, s, masked=(s % 2 == 0))
+        a_h = np.zeros(M, np.uint8)
+        lp_h = np.zeros(M, np.float32)
+        vh = np.ascontiguousarray(data["valid_actions"])
+        H.h_sample(_p(vh), M, 0, C.c_uint64(77), C.c_uint64(s), int(s % 2 == 0),
+                   _p(a_h), _p(lp_h))
+        assert np.array_equal(a_o, a_h)
+        assert lp_o.tobytes() == lp_h.tobytes()
+        env.step(a_o)
+        H.h_step_fast(_p(data), M, 0, _p(a_h), _p(prev_s), _p(prev_v), 1, 0.8, C.c_uint64(0xC0FFEE), C.c_uint64(2 * s + 1))
+        assert data.tobytes() == env._data.tobytes(), s
+        assert H.h_digest(_p(data), M, 0, 1) == env.digest()
+        assert H.h_digest(_p(data), M, 0, 0) == env.digest(with_id=False)
+    assert gc.value == env._game_count and gc.value > M  # some games ended and were re-dealt
+
+
+def test_sampler_statistics(oracle):
+    """uniform over valid actions (policy/random.py:17-27 semantics); logp = -log(#valid)."""
+    M = 200000
+    rng = np.random.default_rng(1)
+    valid = (rng.random((M, 4)) < 0.6).astype(np.uint8)
+    a, lp = oracle.sample_actions(valid, 5, 9, masked=True)
+    cnt = valid.sum(axis=1)
+    has = cnt > 0
+    assert np.all(valid[np.arange(M)[has], a[has]] == 1)
+    assert np.all(a[~has] == 0) and np.all(lp[~has] == 0)
+    np.testing.assert_allclose(lp[has], -np.log(cnt[has]).astype(np.float32), rtol=1e-6)
+    sel = np.flatnonzero((valid == [1, 1, 1, 1]).all(axis=1))
+    freq = np.bincount(a[sel], minlength=4) / sel.size
+    assert np.all(np.abs(freq - 0.25) < 0.01)
+
+
+def test_philox_matches_oracle(H, oracle):
+    rng = np.random.default_rng(2)
+    for _ in range(64):
+        ctr = rng.integers(0, 2**32, size=4, dtype=np.uint64).astype(np.uint32)
+        key = rng.integers(0, 2**32, size=2, dtype=np.uint64).astype(np.uint32)
+        out = np.zeros(4, np.uint32)
+        H.h_philox(_p(ctr), _p(key), _p(out))
+        assert np.array_equal(out, oracle.philox(ctr, key))
