@@ -125,7 +125,7 @@ def test_sampler_vs_oracle(amd, oracle, torch_cuda, masked):
         cnt = valid.sum(axis=1)
         has = cnt > 0
         ref_lp = torch.distributions.Categorical(probs=torch.from_numpy(valid[has]).float()).log_prob(a2.cpu()[has])
-        assert torch.allclose(lp2.cpu()[has], ref_lp, rtol=1e-6, atol=1e-7)  # fp32 tolerance 1e-6
+        assert torch.allclose(lp2.cpu()[has], ref_lp, rtol=1e-6, atol=2.5e-7)  # fp32; torch clamps p=1 to 1-eps, so log p = -1.2e-7 there
 
 
 def _run_pair(amd, oracle, M, N, seed, reward, *, masked=False, check_every=1, full_every=16, spawn="table",
