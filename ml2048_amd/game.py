@@ -384,12 +384,15 @@ class VecGame:
 
     # ------------------------------------------------------------------------------------------
     def rollout(self, n_steps: int, *, masked: bool = True, act_seed: int = 0, act_counter: int = 0,
-                record_actions: bool = False, digests: bool = False, finish_ids: bool = True):
+                record_actions: bool = False, digests: bool = False, finish_ids: bool = True,
+                kernel_events: Optional[tuple] = None):
         """N x {prepare; uniform-random actions; step} fused into one kernel launch, bit-exact
         with the per-step API on the same seeds (table spawn mode only).
 
         Returns a dict: actions (N,M) uint8 | None, digests (N,) int64 (two's complement of the
         uint64) | None, step_resets (N,) int32 | None.
+        kernel_events: optional (start, end) torch.cuda.Event pair recorded on the launch stream
+        immediately around the rollout kernel (bench.py times the dominant kernel with it).
         """
         if self._spawn != "table":
             raise ValueError("rollout() is defined for spawn='table'")
@@ -420,11 +423,15 @@ class VecGame:
         actions = torch.empty((N, M), dtype=torch.uint8, device=dev) if record_actions else None
         dig = torch.zeros((N,), dtype=torch.int64, device=dev) if digests else None
         with torch.cuda.device(dev):
+            if kernel_events is not None:
+                kernel_events[0].record(torch.cuda.current_stream(dev))
             _lib.check(L.ml2048_rollout(
                 self._stream(), M, self._idx_base, self._st(), N, perm_dev.data_ptr(), mask_dev.data_ptr(),
                 len(epochs), sched_dev.data_ptr(), self._reward_kind, int(masked), int(act_seed), int(act_counter),
                 actions.data_ptr() if actions is not None else None, dig.data_ptr() if dig is not None else None,
                 flags.data_ptr(), last.data_ptr()), "rollout")
+            if kernel_events is not None:
+                kernel_events[1].record(torch.cuda.current_stream(dev))
             step_resets = None
             if finish_ids:
                 step_resets = torch.empty((N,), dtype=torch.int32, device=dev)
