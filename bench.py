@@ -53,6 +53,18 @@ def parse():
     return ap.parse_args()
 
 
+def host_cpu_share() -> int:
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(M: int, N: int, seed: int, seconds: float):
     """Time the CPU oracle on the host cores: repeated N-step rollouts of M boards (same seeds,
     same action stream definition) until ~`seconds` have elapsed."""
@@ -70,7 +82,8 @@ def cpu_baseline(M: int, N: int, seed: int, seconds: float):
         orc._lib = orc.lib(lib_path)
     except Exception:
         orc.build()
-    threads = int(orc.lib().orc_num_threads())
+    threads = host_cpu_share()
+    orc.lib().orc_set_num_threads(threads)
     env = orc.OracleVecGame(M, "normal")
     env.reset(seed)
     counter = 0
@@ -89,17 +102,30 @@ def cpu_baseline(M: int, N: int, seed: int, seconds: float):
     while True:
         one_rollout()
         reps += 1
-        if time.perf_counter() - t0 >= seconds or reps >= 10000:
+        if time.perf_counter() - t0 >= seconds * 0.75 or reps >= 10000:
             break
     dt = time.perf_counter() - t0
+    # single-thread figure on a smaller slice of the same workload
+    orc.lib().orc_set_num_threads(1)
+    t1 = time.perf_counter()
+    reps1 = 0
+    while True:
+        one_rollout()
+        reps1 += 1
+        if time.perf_counter() - t1 >= seconds * 0.25 or reps1 >= 10000:
+            break
+    dt1 = time.perf_counter() - t1
+    orc.lib().orc_set_num_threads(threads)
     try:
         cpu = subprocess.check_output("lscpu | grep 'Model name' | head -1", shell=True, text=True).split(":")[-1].strip()
     except Exception:
         cpu = "unknown"
     return {
         "value": M * N * reps / dt, "unit": "board-steps/s", "cores": threads, "kind": "port",
+        "value_1thread": M * N * reps1 / dt1,
         "sample": f"{reps} x (M={M} boards x N={N} steps) in {dt:.1f}s: C/OpenMP restatement of game_numba "
-                  f"(bit-exact oracle, not numba; native prepare loop), {os.cpu_count()} logical CPUs, {cpu}",
+                  f"(bit-exact oracle, not numba; native prepare loop; Python driver loop per env step as in the "
+                  f"reference), {threads} OpenMP threads = this box's CPU share of {os.cpu_count()} logical CPUs, {cpu}",
     }
 
 
@@ -140,7 +166,8 @@ def main():
     def bench_step(timed: bool):
         if args.mode == "fused":
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if timed else None
-            env.rollout(N, masked=bool(args.masked), act_seed=7 + rank, act_counter=counter[0], kernel_events=ev)
+            env.rollout(N, masked=bool(args.masked), act_seed=7 + rank, act_counter=counter[0], kernel_events=ev,
+                        prefetch_next=True)
             counter[0] += N
             if ev:
                 kern_ms.append(ev)

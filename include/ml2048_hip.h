@@ -155,6 +155,28 @@ int ml2048_debug_philox(void *stream, int64_t n, int64_t idx_base, uint64_t seed
                         uint32_t *out);
 
 /*
+ * Host RNG schedule for the bit-exact spawn mode, drawn ahead for n_steps env steps (HOST memory
+ * only; no GPU work).  Restates the numpy Generator(PCG64) calls VecGame makes per prepare()/step()
+ * (game_numba.py:589-591, 622-626, 670) so that N steps cost one C call instead of 3N numpy calls.
+ *   rng           PCG64 state as numpy exposes it (bit_generator.state), updated in place
+ *   randperm/randfloat  the host tables (uint8[1024][16], float[1024]), regenerated in place
+ *   rand_step     VecGame._rand_step, updated in place
+ *   schedule      int32[n_steps][3] out: {epoch index, row_base of prepare, row_base of step}
+ *   perm_epochs   uint8[max_epochs][1024][16] out: epoch 0 = the tables at entry, then one per
+ *                 regeneration;  two_masks uint32[max_epochs] out;  n_epochs out
+ * Returns ML2048_E_UNSUPPORTED if more than max_epochs tables would be needed (state is then
+ * unspecified: size max_epochs as n_steps + 1 to make that impossible).
+ */
+typedef struct ml2048_pcg64 {
+    uint64_t state_hi, state_lo, inc_hi, inc_lo;
+    int32_t has_uint32;
+    uint32_t uinteger;
+} ml2048_pcg64;
+int ml2048_hostrng_schedule(ml2048_pcg64 *rng, uint8_t *randperm, float *randfloat, int32_t *rand_step,
+                            int32_t n_steps, double two_prob, int32_t *schedule, uint8_t *perm_epochs,
+                            uint32_t *two_masks, int32_t max_epochs, int32_t *n_epochs);
+
+/*
  * Fused N-step rollout with on-device action sampling: the random-action loop
  *     for t in range(N): env.prepare(); a = policy.sample_actions(...); env.step(a)
  * (VecRunner.step_many with RandomPolicy, src/ml2048/runner.py:74-117, policy/random.py:17-27)

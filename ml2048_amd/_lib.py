@@ -25,6 +25,13 @@ class Ml2048Error(RuntimeError):
     pass
 
 
+class Pcg64State(C.Structure):
+    """struct ml2048_pcg64 (include/ml2048_hip.h)."""
+
+    _fields_ = [("state_hi", C.c_uint64), ("state_lo", C.c_uint64), ("inc_hi", C.c_uint64), ("inc_lo", C.c_uint64),
+                ("has_uint32", C.c_int32), ("uinteger", C.c_uint32)]
+
+
 _lib = None
 
 _SIGNATURES = {
@@ -49,6 +56,9 @@ _SIGNATURES = {
     "ml2048_unpack_records": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(State), C.c_void_p]),
     "ml2048_digest": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_int, C.c_void_p]),
     "ml2048_debug_philox": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "ml2048_hostrng_schedule": (C.c_int, [C.POINTER(Pcg64State), C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32,
+                                          C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                          C.POINTER(C.c_int32)]),
     "ml2048_rollout_flag_words": (C.c_int64, [C.c_int64]),
     "ml2048_rollout_scratch_ints": (C.c_int64, [C.c_int64, C.c_int32]),
     "ml2048_rollout": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_int32, C.c_void_p,

@@ -208,10 +208,12 @@ class VecGame:
     def _upload_tables(self) -> None:
         self._randperm_dev.copy_(torch.from_numpy(self._rng.randperm))
         self._randfloat_dev.copy_(torch.from_numpy(self._rng.randfloat))
+        self._tables_dirty = False
 
     # reference-visible private attributes
     @property
     def _rand_step(self) -> int:
+        self._drop_prefetch()
         return self._rng.rand_step
 
     @property
@@ -254,8 +256,42 @@ class VecGame:
             _lib.check(self._L.ml2048_unpack_records(self._stream(), self._size, self._st(), dev.data_ptr()), "unpack_records")
 
     # ------------------------------------------------------------------------------------------
+    # ---- schedule prefetch (fused rollouts) --------------------------------------------------
+    # A worker thread may draw the NEXT rollout's host schedule on a CLONE of the host RNG while
+    # the GPU runs the current one (the native draw releases the GIL).  The clone replaces
+    # self._rng only when that schedule is actually consumed, so dropping it is always safe.
+    def _drop_prefetch(self) -> None:
+        fut = getattr(self, "_prefetch", None)
+        if fut is not None:
+            fut[1].result()  # let the worker finish; its clone is simply discarded
+            self._prefetch = None
+
+    def _start_prefetch(self, n: int) -> None:
+        import concurrent.futures as cf
+
+        if getattr(self, "_pool", None) is None:
+            self._pool = cf.ThreadPoolExecutor(max_workers=1, thread_name_prefix="ml2048-hostrng")
+        clone = self._rng.clone()
+        two_prob = self._two_prob
+
+        def work():
+            return clone, clone.draw_schedule(n, two_prob)
+
+        self._prefetch = (n, self._pool.submit(work))
+
+    def _next_schedule(self, n: int):
+        fut = getattr(self, "_prefetch", None)
+        self._prefetch = None
+        if fut is not None:
+            clone, drawn = fut[1].result()
+            if fut[0] == n:
+                self._rng = clone
+                return drawn
+        return self._rng.draw_schedule(n, self._two_prob)
+
     def reset(self, seed: Optional[int] = None) -> None:
         """game_numba.py:606-617.  `_game_count` is NOT reset (only the constructor sets it)."""
+        self._drop_prefetch()
         self._rng = HostRng(seed)
         self._fast_counter = 0
         self._upload_tables()
@@ -274,10 +310,11 @@ class VecGame:
         """prepare() without a host sync: (reset_indices buffer (M,) int64, n_reset (1,) int32);
         the first n_reset entries of the buffer are the ascending re-dealt slots."""
         L, M = self._L, self._size
+        self._drop_prefetch()
         with torch.cuda.device(self.device):
             if self._spawn == "table":
                 regen, row_base = self._rng.draw_prepare()  # :622-626, drawn unconditionally
-                if regen:
+                if regen or self._tables_dirty:
                     self._upload_tables()
                 rc = L.ml2048_prepare(
                     self._stream(), M, self._idx_base, self._st(), self._randperm_dev.data_ptr(),
@@ -314,8 +351,11 @@ class VecGame:
         """step() on device tensors; the result aliases live state (like the reference's views)."""
         a = self._as_device_actions(actions)
         L, M = self._L, self._size
+        self._drop_prefetch()
         with torch.cuda.device(self.device):
             if self._spawn == "table":
+                if self._tables_dirty:
+                    self._upload_tables()
                 row_base = self._rng.draw_step()  # :670
                 rc = L.ml2048_step(self._stream(), M, self._idx_base, self._st(), a.data_ptr(), _ACT_CODE[a.dtype],
                                    self._reward_kind, self._two_prob, row_base, self._randperm_dev.data_ptr(),
@@ -385,7 +425,7 @@ class VecGame:
     # ------------------------------------------------------------------------------------------
     def rollout(self, n_steps: int, *, masked: bool = True, act_seed: int = 0, act_counter: int = 0,
                 record_actions: bool = False, digests: bool = False, finish_ids: bool = True,
-                kernel_events: Optional[tuple] = None):
+                kernel_events: Optional[tuple] = None, prefetch_next: bool = False):
         """N x {prepare; uniform-random actions; step} fused into one kernel launch, bit-exact
         with the per-step API on the same seeds (table spawn mode only).
 
@@ -393,28 +433,30 @@ class VecGame:
         uint64) | None, step_resets (N,) int32 | None.
         kernel_events: optional (start, end) torch.cuda.Event pair recorded on the launch stream
         immediately around the rollout kernel (bench.py times the dominant kernel with it).
+        prefetch_next: draw the host schedule of the next rollout(n_steps) on a worker thread while
+        this one runs on the GPU (results are identical either way).
         """
         if self._spawn != "table":
             raise ValueError("rollout() is defined for spawn='table'")
         N, M, dev = int(n_steps), self._size, self.device
         if N <= 0:
             raise ValueError(f"n_steps={n_steps}")
-        # pre-draw the host schedule (independent of game state)
-        epochs = [self._rng.randperm.copy()]
-        masks = [self._rng.two_mask(self._two_prob)]
-        sched = np.empty((N, 3), dtype=np.int32)
-        for t in range(N):
-            regen, row_p = self._rng.draw_prepare()
-            if regen:
-                epochs.append(self._rng.randperm.copy())
-                masks.append(self._rng.two_mask(self._two_prob))
-            row_s = self._rng.draw_step()
-            sched[t] = (len(epochs) - 1, row_p, row_s)
-        perm_dev = torch.from_numpy(np.stack(epochs)).to(dev)
-        mask_dev = torch.from_numpy(np.array(masks, dtype=np.uint32).view(np.int32)).to(dev)
-        sched_dev = torch.from_numpy(sched).to(dev)
-        if len(epochs) > 1:
-            self._upload_tables()  # leave the device tables equal to the host's current ones
+        # the host schedule (independent of game state): one native call, or already drawn ahead
+        sched, epochs, masks = self._next_schedule(N)
+        # one packed H2D copy: [epoch tables | schedule | masks], each section 16-byte aligned
+        E = epochs.shape[0]
+        o_sched = E * RAND_SIZE * 16
+        o_mask = o_sched + ((N * 12 + 15) // 16) * 16
+        packed = np.empty((o_mask + E * 4,), dtype=np.uint8)
+        packed[:o_sched] = epochs.reshape(-1)
+        packed[o_sched:o_sched + N * 12] = sched.view(np.uint8).reshape(-1)
+        packed[o_mask:] = masks.view(np.uint8)
+        packed_dev = torch.from_numpy(packed).to(dev)
+        perm_dev = packed_dev[:o_sched]
+        sched_dev = packed_dev[o_sched:o_sched + N * 12]
+        mask_dev = packed_dev[o_mask:]
+        if E > 1:
+            self._tables_dirty = True  # device copies of the tables are refreshed lazily (per-step API)
 
         L = self._L
         W = int(L.ml2048_rollout_flag_words(M))
@@ -427,7 +469,7 @@ class VecGame:
                 kernel_events[0].record(torch.cuda.current_stream(dev))
             _lib.check(L.ml2048_rollout(
                 self._stream(), M, self._idx_base, self._st(), N, perm_dev.data_ptr(), mask_dev.data_ptr(),
-                len(epochs), sched_dev.data_ptr(), self._reward_kind, int(masked), int(act_seed), int(act_counter),
+                E, sched_dev.data_ptr(), self._reward_kind, int(masked), int(act_seed), int(act_counter),
                 actions.data_ptr() if actions is not None else None, dig.data_ptr() if dig is not None else None,
                 flags.data_ptr(), last.data_ptr()), "rollout")
             if kernel_events is not None:
@@ -441,5 +483,7 @@ class VecGame:
                     self._game_count_dev.data_ptr(), step_resets.data_ptr(), scratch.data_ptr()), "rollout_finish_ids")
         # every temporary above was allocated on the launch stream, so the caching allocator's
         # stream-ordered reuse keeps them valid until the kernels have consumed them
+        if prefetch_next:
+            self._start_prefetch(N)
         return {"actions": actions, "digests": dig, "step_resets": step_resets,
                 "reset_flags": flags, "last_reset": last}

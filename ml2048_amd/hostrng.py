@@ -9,6 +9,7 @@ whole fused rollout.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Optional
 
 import numpy as np
@@ -25,6 +26,18 @@ class HostRng:
         self.randperm[:, :] = np.arange(16).reshape((1, 16))  # :610
         self.epoch = 0  # number of table regenerations so far (bookkeeping only)
         self._reset_rand()  # :611
+
+    def clone(self) -> "HostRng":
+        """Independent copy at the same point of the stream (used to draw a schedule ahead on a
+        worker thread without touching this object)."""
+        c = object.__new__(HostRng)
+        c.rand = np.random.Generator(type(self.rand.bit_generator)())
+        c.rand.bit_generator.state = self.rand.bit_generator.state
+        c.rand_step = self.rand_step
+        c.randperm = self.randperm.copy()
+        c.randfloat = self.randfloat.copy()
+        c.epoch = self.epoch
+        return c
 
     # game_numba.py:589-591 - permuted() works in place, so successive tables compose
     def _reset_rand(self) -> None:
@@ -59,3 +72,61 @@ class HostRng:
             if float(self.randfloat[c]) < two_prob:
                 m |= 1 << c
         return m
+
+    def draw_schedule(self, n_steps: int, two_prob: float):
+        """Pre-draw n_steps x {draw_prepare; draw_step} in one native call
+        (ml2048_hostrng_schedule).  Returns (schedule int32[N,3], perm_epochs uint8[E,1024,16],
+        two_masks uint32[E]); epoch 0 is the table in force at entry.  Leaves this object (numpy
+        generator state, tables, rand_step) exactly where N python-level draws would."""
+        from . import _lib
+
+        L = _lib.load()
+        n = int(n_steps)
+        bg = self.rand.bit_generator
+        st = bg.state
+        if st["bit_generator"] != "PCG64":  # default_rng is PCG64; anything else: python path
+            return self._draw_schedule_py(n, two_prob)
+        s, inc = st["state"]["state"], st["state"]["inc"]
+        mask64 = (1 << 64) - 1
+        c = _lib.Pcg64State(s >> 64, s & mask64, inc >> 64, inc & mask64, int(st["has_uint32"]), int(st["uinteger"]))
+        # a regeneration happens with probability 0.1 per step; n + 1 epochs can never overflow
+        cap = n + 1 if n <= 64 else max(16, n // 4 + 8)
+        while True:
+            sched = np.empty((n, 3), dtype=np.int32)
+            epochs = np.empty((cap, RAND_SIZE, 16), dtype=np.uint8)
+            masks = np.empty((cap,), dtype=np.uint32)
+            rs = C.c_int32(self.rand_step)
+            ne = C.c_int32(0)
+            perm, flt = self.randperm.copy(), self.randfloat.copy()
+            cc = _lib.Pcg64State.from_buffer_copy(c)
+            rc = L.ml2048_hostrng_schedule(C.byref(cc), perm.ctypes.data, flt.ctypes.data, C.byref(rs), n,
+                                           float(two_prob), sched.ctypes.data, epochs.ctypes.data,
+                                           masks.ctypes.data, cap, C.byref(ne))
+            if rc == -3 and cap < n + 1:  # ML2048_E_UNSUPPORTED: epoch buffer too small - retry larger
+                cap = n + 1
+                continue
+            _lib.check(rc, "hostrng_schedule")
+            break
+        self.randperm[...] = perm
+        self.randfloat[...] = flt
+        self.rand_step = int(rs.value)
+        self.epoch += int(ne.value) - 1
+        st["state"]["state"] = (int(cc.state_hi) << 64) | int(cc.state_lo)
+        st["has_uint32"] = int(cc.has_uint32)
+        st["uinteger"] = int(cc.uinteger)
+        bg.state = st
+        k = int(ne.value)
+        return sched, epochs[:k], masks[:k]
+
+    def _draw_schedule_py(self, n: int, two_prob: float):
+        epochs = [self.randperm.copy()]
+        masks = [self.two_mask(two_prob)]
+        sched = np.empty((n, 3), dtype=np.int32)
+        for t in range(n):
+            regen, row_p = self.draw_prepare()
+            if regen:
+                epochs.append(self.randperm.copy())
+                masks.append(self.two_mask(two_prob))
+            row_s = self.draw_step()
+            sched[t] = (len(epochs) - 1, row_p, row_s)
+        return sched, np.stack(epochs), np.array(masks, dtype=np.uint32)

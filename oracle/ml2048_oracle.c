@@ -18,6 +18,14 @@
 
 int orc_abi_version(void) { return 1; }
 
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

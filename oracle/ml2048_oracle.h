@@ -52,6 +52,7 @@ typedef struct orc_record {
 
 int orc_abi_version(void);
 int orc_num_threads(void);
+void orc_set_num_threads(int n);
 
 /* game_numba.py:48-90.  `buckets` may be NULL; otherwise it must have room for index `num`
  * (up to 17 for an 18-symbol line; the reference's 16-slot `merged` overflows for num==16, H9). */

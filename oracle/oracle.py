@@ -71,6 +71,7 @@ def _bind(L: C.CDLL) -> C.CDLL:
     vp, i64, i32, u64, dbl = C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_double
     L.orc_abi_version.restype = i32
     L.orc_num_threads.restype = i32
+    L.orc_set_num_threads.argtypes = [i32]
     L.orc_push_row.argtypes = [vp, i32, i32, vp]
     L.orc_lines18_table.argtypes = [vp, vp, vp]
     L.orc_step_kernel.argtypes = [vp, vp, i64]
