@@ -193,10 +193,9 @@ def main():
         bench_step(True)
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from ml2048_amd.shard import max_over_ranks
+
+    dt = max_over_ranks(dt, dist)
 
     total_board_steps = world * M * N * K
     value = total_board_steps / dt
