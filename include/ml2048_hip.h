@@ -110,7 +110,8 @@ int ml2048_step_fast(void *stream, int64_t M, int64_t idx_base, const ml2048_sta
  * Uniform action sampling (RandomPolicy.sample_actions, src/ml2048/policy/random.py:17-27 with
  * categorical_sample, src/ml2048/stats.py:32-47: uniform over the valid actions, log-prob
  * -log(#valid)).  torch.multinomial's stream is not reproducible across devices, so the stream is
- * defined here: word = Philox4x32-10(key = seed, counter = {counter, idx_base + idx})[0];
+ * defined here: word = word (counter & 3) of Philox4x32-10(key = seed, counter = {counter >> 2,
+ * idx_base + idx}) = rocRAND's sequence rocrand_init(seed, idx_base + idx, offset = counter);
  * masked: action = the ((word * cnt) >> 32)-th valid action in L,R,U,D order (cnt == 0 -> 0);
  * unmasked: action = word & 3.   actions: uint8[M]; logp: float[M] or NULL.
  */

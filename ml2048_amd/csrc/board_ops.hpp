@@ -43,6 +43,15 @@ ML_HD uint32_t perm_b32(uint32_t hi, uint32_t lo, uint32_t sel) {
 
 ML_HD uint32_t bswap32(uint32_t x) { return perm_b32(0, x, 0x00010203u); }
 
+// bit-field extract (v_bfe_u32): (x >> offset) & ((1 << width) - 1), offset taken mod 32
+ML_HD uint32_t ubfe(uint32_t x, uint32_t offset, uint32_t width) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ubfe(x, offset, width);
+#else
+    return (x >> (offset & 31u)) & ((1u << width) - 1u);
+#endif
+}
+
 // 0x80 in every byte of x that is non-zero (bytes must be <= 0x80)
 ML_HD uint32_t nz_bytes(uint32_t x) { return (x + 0x7F7F7F7Fu) & 0x80808080u; }
 // 0x80 in every byte of x that is zero
@@ -163,6 +172,31 @@ ML_HD MergeStats merge_stats(uint32_t mexp_first, uint32_t mexp_second) {
     return s;
 }
 
+// the reward-relevant sums only (no bucket array): what a fused rollout needs every step
+ML_HD void merge_sums(uint32_t mexp_first, uint32_t mexp_second, int kind, uint32_t &sum_value,
+                      uint32_t &sum_rank, uint32_t &count) {
+    sum_value = sum_rank = count = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t word = (k < 4) ? mexp_first : mexp_second;
+        const uint32_t num = ubfe(word, 8u * (k & 3), 8);
+        const uint32_t ok = (num - 1u) < 15u;
+        sum_value += ok ? (2u << num) : 0u;
+        if (kind == 2) sum_rank += ok ? (num + 1u) : 0u;
+        if (kind == 3) count += ok;
+    }
+}
+
+// merged[16] byte counters from the merge exponents of one move
+ML_HD void merge_buckets(uint32_t mexp_first, uint32_t mexp_second, uint32_t merged[4]) {
+    merged[0] = merged[1] = merged[2] = merged[3] = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t word = (k < 4) ? mexp_first : mexp_second;
+        add_bucket(merged, ubfe(word, 8u * (k & 3), 8));
+    }
+}
+
 // ---- valid-action mask (reference _line_movable / _compute_valid_actions, :215-289) -----------
 // forward  (toward index 0)  <=> exists i: n[i+1] != 0 and (n[i] == 0 or n[i] == n[i+1])
 // backward (toward index 3)  <=> exists i: n[i]   != 0 and (n[i+1] == 0 or n[i] == n[i+1])
@@ -214,22 +248,33 @@ ML_HD void set_cell(Board &b, uint32_t cell, uint32_t value) {
 // (randfloat is indexed by the CELL, :207, hazard H1).  Places up to `count` tiles.
 ML_HD void spawn_table(Board &b, const uint32_t perm[4], uint32_t two_mask, int count) {
     const uint32_t empties = empty_mask(b);
-    const uint64_t plo = (uint64_t)perm[0] | ((uint64_t)perm[1] << 32);
-    const uint64_t phi = (uint64_t)perm[2] | ((uint64_t)perm[3] << 32);
-    uint32_t hits = 0; // bit i <=> cell perm[i] is empty
+    uint32_t hits = 0; // bit i <=> cell perm[i] is empty: bfe (cell), bfe (its empty bit), lshl_or
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        uint32_t c = (perm[i >> 2] >> (8 * (i & 3))) & 0xFu;
-        hits |= ((empties >> c) & 1u) << i;
+        const uint32_t c = ubfe(perm[i >> 2], 8u * (i & 3), 4);
+        hits |= ubfe(empties, c, 1) << i;
     }
     for (int n = 0; n < count; ++n) {
         if (hits == 0) break;
-        uint32_t i = (uint32_t)__builtin_ctz(hits);
+        const uint32_t i = (uint32_t)__builtin_ctz(hits);
         hits &= hits - 1u;
-        uint64_t half = (i & 8u) ? phi : plo;
-        uint32_t c = (uint32_t)(half >> (8u * (i & 7u))) & 0xFu;
-        set_cell(b, c, ((two_mask >> c) & 1u) ? 1u : 2u);
+        const uint32_t q = i >> 2;
+        uint32_t w = perm[0];
+        w = q == 1u ? perm[1] : w;
+        w = q == 2u ? perm[2] : w;
+        w = q == 3u ? perm[3] : w;
+        const uint32_t c = ubfe(w, 8u * (i & 3u), 4);
+        set_cell(b, c, 2u - ubfe(two_mask, c, 1));
     }
+}
+
+// the two tiles of a freshly dealt (empty) board: the first two entries of the permutation row
+// (VecGame.prepare's `_spawn2(..., 2)` on a zeroed record, game_numba.py:639-655)
+ML_HD void deal_table(Board &b, const uint32_t perm[4], uint32_t two_mask) {
+    const uint32_t c1 = perm[0] & 0xFu, c2 = (perm[0] >> 8) & 0xFu;
+    b.r[0] = b.r[1] = b.r[2] = b.r[3] = 0;
+    set_cell(b, c1, 2u - ubfe(two_mask, c1, 1));
+    set_cell(b, c2, 2u - ubfe(two_mask, c2, 1));
 }
 
 // ---- counter-based spawn (fast mode; build-defined, equals oracle orc_step_fast) --------------
@@ -316,6 +361,25 @@ ML_HD bool step_pre(StepRegs &s, uint32_t action, int reward_kind) {
     return true;
 }
 
+// step_pre without the bucket array: s.merged is NOT touched; the caller keeps (mexp_first,
+// mexp_second) and derives merged[16] with merge_buckets() when it is actually needed.
+ML_HD bool step_pre_lite(StepRegs &s, uint32_t action, int reward_kind, uint32_t &mexp_first,
+                         uint32_t &mexp_second) {
+    bool ok = action < 4u && ((s.valid >> (8u * (action & 3u))) & 0xFFu) != 0u;
+    if (!ok) return false;
+    Board prev = s.board;
+    MoveResult mv = move_board(prev, action);
+    MergeStats st;
+    merge_sums(mv.mexp_first, mv.mexp_second, reward_kind, st.sum_value, st.sum_rank, st.count);
+    mexp_first = mv.mexp_first;
+    mexp_second = mv.mexp_second;
+    s.board = mv.board;
+    s.step += 1;
+    s.reward = (float)reward_value(reward_kind, mv.board, prev, st);
+    s.score = (float)((double)s.score + (double)st.sum_value);
+    return true;
+}
+
 ML_HD void step_post(StepRegs &s) {
     s.valid = valid_actions(s.board);
     s.terminated = s.valid == 0u;
@@ -358,6 +422,15 @@ ML_HD U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
 ML_HD U4 philox_at(uint64_t seed, uint64_t counter, uint64_t idx) {
     U4 c = {(uint32_t)counter, (uint32_t)(counter >> 32), (uint32_t)idx, (uint32_t)(idx >> 32)};
     return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// The action sampler's word for call-counter t: word (t & 3) of Philox block (t >> 2) of
+// subsequence idx - i.e. rocRAND's own sequence at offset t (rocrand_init(seed, idx, t)); four
+// consecutive steps share one Philox evaluation in the fused rollout.
+ML_HD uint32_t sampler_word(uint64_t seed, uint64_t t, uint64_t idx) {
+    U4 r = philox_at(seed, t >> 2, idx);
+    const uint32_t k = (uint32_t)(t & 3u);
+    return k == 0 ? r.x : k == 1 ? r.y : k == 2 ? r.z : r.w;
 }
 
 // masked-uniform / uniform action from one random word (oracle orc_sample_actions)

@@ -97,9 +97,11 @@ __device__ __forceinline__ void rocrand_words(uint64_t seed, uint64_t counter, u
     w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
 }
 
-__device__ __forceinline__ uint32_t rocrand_word0(uint64_t seed, uint64_t counter, uint64_t idx) {
+// the action sampler's word for call-counter t: rocRAND's sequence of subsequence idx at offset t
+// (= word t&3 of Philox block t>>2; board_ops.hpp sampler_word)
+__device__ __forceinline__ uint32_t rocrand_sampler_word(uint64_t seed, uint64_t t, uint64_t idx) {
     rocrand_state_philox4x32_10 s;
-    rocrand_init(seed, idx, counter * 4ull, &s);
+    rocrand_init(seed, idx, t, &s);
     return rocrand(&s);
 }
 
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(kPrepBlock) void k_prep_deal(ml2048_state st, int64
     } else {
         uint32_t perm[4];
         load_perm_row(randperm, row_base + idx_base + i, perm);
-        spawn_table(s.board, perm, two_mask, 2); // :648-655
+        deal_table(s.board, perm, two_mask); // :648-655 on the zeroed board
     }
     s.valid = valid_actions(s.board); // :656
 
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(kBlock) void k_sample(const uint8_t *__restrict__ v
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= M) return;
     const uint32_t v = masked ? reinterpret_cast<const uint32_t *>(valid)[i] : 0x01010101u;
-    const uint32_t word = rocrand_word0(seed, counter, (uint64_t)(idx_base + i));
+    const uint32_t word = rocrand_sampler_word(seed, counter, (uint64_t)(idx_base + i));
     uint32_t cnt;
     const uint32_t a = pick_action(v, word, masked, cnt);
     actions[i] = (uint8_t)a;
@@ -497,6 +499,11 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
     Board prev_board = load_board(st.prev_board, ii);
     uint32_t prev_valid = reinterpret_cast<const uint32_t *>(st.prev_valid)[ii];
     int32_t last = -1;
+    // The merged[16] counters are only observable at the end (and in the optional digests), so
+    // the loop carries the <= 8 merge exponents of the last valid move and expands them lazily.
+    uint32_t mexp_first = 0, mexp_second = 0;
+    bool merged_stale = false; // true once s.merged no longer reflects (mexp_first, mexp_second)
+    uint32_t aw[4] = {0, 0, 0, 0}; // the sampler's current Philox block (4 consecutive steps)
 
     for (int t = 0; t < N; ++t) {
         const int epoch = schedule[3 * t + 0];
@@ -512,21 +519,32 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
         if (deal) {
             clear_regs(s);
             invalid = 0;
+            mexp_first = mexp_second = 0;
+            merged_stale = true;
             uint32_t perm[4];
             load_perm_row(table, row_p + idx_base + ii, perm);
-            spawn_table(s.board, perm, two_mask, 2);
+            deal_table(s.board, perm, two_mask);
             s.valid = valid_actions(s.board);
             last = t;
         }
-        // ---- sample (policy/random.py:17-27)
-        const uint32_t word = rocrand_word0(act_seed, act_counter0 + (uint64_t)t, (uint64_t)(idx_base + ii));
+        // ---- sample (policy/random.py:17-27): one Philox block serves 4 consecutive steps
+        const uint64_t tt = act_counter0 + (uint64_t)t;
+        if (t == 0 || (tt & 3ull) == 0) {
+            rocrand_state_philox4x32_10 rs;
+            rocrand_init(act_seed, (uint64_t)(idx_base + ii), tt & ~3ull, &rs);
+            const uint4 v = rocrand4(&rs);
+            aw[0] = v.x; aw[1] = v.y; aw[2] = v.z; aw[3] = v.w;
+        }
+        const uint32_t k4 = (uint32_t)(tt & 3ull); // wave-uniform
+        const uint32_t word = k4 == 0 ? aw[0] : k4 == 1 ? aw[1] : k4 == 2 ? aw[2] : aw[3];
         uint32_t cnt;
         const uint32_t action = pick_action(masked ? s.valid : 0x01010101u, word, masked, cnt);
         if (actions_out && live) actions_out[(int64_t)t * M + i] = (uint8_t)action;
         // ---- step (game_numba.py:660-738)
         prev_board = s.board;
         prev_valid = s.valid;
-        if (step_pre(s, action, KIND)) {
+        if (step_pre_lite(s, action, KIND, mexp_first, mexp_second)) {
+            merged_stale = true;
             uint32_t perm[4];
             load_perm_row(table, row_s + idx_base + ii, perm);
             spawn_table(s.board, perm, two_mask, 1);
@@ -536,6 +554,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
             invalid = 1;
         }
         if (digests_out) {
+            if (merged_stale) {
+                merge_buckets(mexp_first, mexp_second, s.merged);
+                merged_stale = false;
+            }
             uint64_t h = 0;
             if (live)
                 h = board_digest((uint64_t)(idx_base + i), s.board, s.merged, s.valid, s.terminated, invalid,
@@ -544,6 +566,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
             if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(digests_out + t), (unsigned long long)h);
         }
     }
+    if (merged_stale) merge_buckets(mexp_first, mexp_second, s.merged);
 
     if (!live) return;
     store16(st.board, i, s.board.r);

@@ -336,8 +336,9 @@ void orc_sample_actions(const uint8_t *valid, int64_t valid_stride, int64_t M, i
                         float *logp) {
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < M; ++i) {
-        uint32_t r[4];
-        philox_at(seed, counter, (uint64_t)(idx_base + i), r);
+        uint32_t blk[4];
+        philox_at(seed, counter >> 2, (uint64_t)(idx_base + i), blk);
+        uint32_t r[1] = {blk[counter & 3u]}; /* word (t&3) of block (t>>2): rocRAND offset t */
         if (!masked) {
             actions[i] = (uint8_t)(r[0] & 3u);
             if (logp) logp[i] = neg_log_count(4);

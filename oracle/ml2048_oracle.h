@@ -101,7 +101,8 @@ void orc_hist_maxcell(const uint8_t *board, int64_t board_stride, const uint8_t 
 /* Philox4x32-10 (Salmon et al., SC'11; Random123 v1.14 constants).  ctr/key/out: 4/2/4 words. */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
-/* Action sampler.  word = philox(ctr={counter_lo,counter_hi,idx_lo,idx_hi}, key=seed)[0].
+/* Action sampler.  word = philox(ctr={(counter>>2)_lo,_hi,idx_lo,idx_hi}, key=seed)[counter & 3]
+ * (= rocRAND's Philox sequence of subsequence idx at offset `counter`).
  *  masked=0: action = word & 3, logp = -log(4).
  *  masked=1: cnt = #valid; k = (word * cnt) >> 32; action = k-th set bit in L,R,U,D order;
  *            logp = -logf(cnt); cnt==0 -> action 0, logp 0.

@@ -101,10 +101,14 @@ void h_step(Rec *data, int64_t M, int64_t idx_base, const uint8_t *actions, uint
         memcpy(prev_valid + 4 * i, e.valid, 4);
         StepRegs s;
         load(e, s);
-        if (!step_pre(s, actions[i], reward_kind)) {
+        uint32_t mf, ms;
+        bool ok = (i & 1) ? step_pre(s, actions[i], reward_kind)
+                          : step_pre_lite(s, actions[i], reward_kind, mf, ms); // both forms must agree
+        if (!ok) {
             e.invalid = 1;
             continue;
         }
+        if (!(i & 1)) merge_buckets(mf, ms, s.merged);
         uint32_t perm[4];
         memcpy(perm, randperm + 16 * ((rand_seed + idx_base + i) & 1023), 16);
         spawn_table(s.board, perm, two_mask, 1);
@@ -125,7 +129,10 @@ int64_t h_prepare(Rec *data, int64_t M, int64_t idx_base, int64_t row_base, cons
         clear_regs(s);
         uint32_t perm[4];
         memcpy(perm, randperm + 16 * ((row_base + idx_base + i) & 1023), 16);
-        spawn_table(s.board, perm, two_mask, 2);
+        if (i & 1)
+            spawn_table(s.board, perm, two_mask, 2);
+        else
+            deal_table(s.board, perm, two_mask); // specialised form for an empty board
         s.valid = valid_actions(s.board);
         memset(&e, 0, sizeof(e));
         store(e, s);
@@ -191,9 +198,8 @@ void h_sample(const uint8_t *valid, int64_t M, int64_t idx_base, uint64_t seed, 
     for (int64_t i = 0; i < M; ++i) {
         uint32_t v;
         memcpy(&v, valid + 4 * i, 4);
-        U4 r = philox_at(seed, counter, (uint64_t)(idx_base + i));
         uint32_t cnt;
-        actions[i] = (uint8_t)pick_action(v, r.x, masked, cnt);
+        actions[i] = (uint8_t)pick_action(v, sampler_word(seed, counter, (uint64_t)(idx_base + i)), masked, cnt);
         logp[i] = neg_log_count(cnt);
     }
 }
