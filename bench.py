@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary stepwise measurement")
+    ap.add_argument("--prefetch", type=int, default=0,
+                    help="draw the next rollout's host schedule on a worker thread (default 0: the async kernel "
+                         "launch already overlaps the host schedule of rollout k+1 with the GPU running rollout k)")
     return ap.parse_args()
 
 
@@ -167,7 +170,7 @@ def main():
         if args.mode == "fused":
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if timed else None
             env.rollout(N, masked=bool(args.masked), act_seed=7 + rank, act_counter=counter[0], kernel_events=ev,
-                        prefetch_next=True)
+                        prefetch_next=bool(args.prefetch))
             counter[0] += N
             if ev:
                 kern_ms.append(ev)
