@@ -79,7 +79,7 @@ def cpu_baseline(M: int, N: int, seed: int, seconds: float):
     try:  # a -march=native build for a fair host number (the in-tree .so is generic x86-64-v2)
         tmp = tempfile.mkdtemp(prefix="ml2048_orc_")
         lib_path = os.path.join(tmp, "libml2048_oracle_native.so")
-        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-fopenmp", "-std=c11", "-shared", "-o",
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-ffp-contract=off", "-fPIC", "-fopenmp", "-std=c11", "-shared", "-o",
                                lib_path, os.path.join(ROOT, "oracle", "ml2048_oracle.c"), "-lm"],
                               stderr=subprocess.DEVNULL)
         orc._lib = orc.lib(lib_path)

@@ -212,6 +212,37 @@ int ml2048_rollout_finish_ids(void *stream, int64_t M, const ml2048_state *st, i
                               const uint64_t *reset_flags, const int32_t *last_reset,
                               int32_t *game_count, int32_t *step_resets, int32_t *scratch);
 
+/*
+ * ---- rollout consumers (SURVEY 8f "next" rows) ------------------------------------------------
+ *
+ * One transition slice straight into the trainer's `[use, step, game]` replay buffers with the
+ * REPLAY_SPEC dtypes (src/ml2048/replay.py:10-20), replacing the nine per-step copies of
+ * Trainer.on_stepped (run_train3.py:125-155).  Every output pointer addresses the contiguous
+ * [game] slice of its buffer for the current (use, step); any of them may be NULL (skipped).
+ *   state <- prev_board (int8[M][16])      valid_actions <- prev_valid (bool[M][4])
+ *   next_state <- board                    next_valid_actions <- valid
+ *   reward (f32), terminated (bool = uint8 0/1), step (int32) <- the record fields
+ *   action (int8[M]) <- actions (uint8[M]);  action_log_prob (f32[M]) <- logp
+ */
+int ml2048_record_transition(void *stream, int64_t M, const ml2048_state *st, const uint8_t *actions,
+                             const float *logp, int8_t *state, uint8_t *valid_actions, int8_t *action,
+                             float *action_log_prob, float *reward, int8_t *next_state,
+                             uint8_t *next_valid_actions, int32_t *step, uint8_t *terminated);
+
+/*
+ * Generalized advantage estimation over the step dimension (compute_gae, src/ml2048/gae.py:50,
+ * :58-68).  Tensors are [U][S][G] contiguous float32 (terminated: uint8/bool):
+ *     delta = gamma * v1 * (!terminated) + reward - v0                                    (:50)
+ *     tmp = 0;  for s = S-1..0:  tmp = delta[:, s] + (tmp * (gamma*lambda)) * (!terminated[:, s]);
+ *                                adv[:, s] = tmp                                        (:65-68)
+ * with the reference's float32 operation order (no fused multiply-add; gamma and the python-float
+ * product gamma*lambda each rounded once to float32, as torch does with python scalars), so the
+ * result equals the torch expression bit for bit.  delta_out may be NULL.
+ */
+int ml2048_gae(void *stream, int64_t U, int64_t S, int64_t G, const float *v0, const float *v1,
+               const float *reward, const uint8_t *terminated, double gamma, double lambda_, float *adv,
+               float *delta_out);
+
 #ifdef __cplusplus
 }
 #endif

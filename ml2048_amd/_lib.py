@@ -59,6 +59,9 @@ _SIGNATURES = {
     "ml2048_hostrng_schedule": (C.c_int, [C.POINTER(Pcg64State), C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int32,
                                           C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                           C.POINTER(C.c_int32)]),
+    "ml2048_record_transition": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(State)] + [C.c_void_p] * 11),
+    "ml2048_gae": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "ml2048_rollout_flag_words": (C.c_int64, [C.c_int64]),
     "ml2048_rollout_scratch_ints": (C.c_int64, [C.c_int64, C.c_int32]),
     "ml2048_rollout": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_int32, C.c_void_p,

@@ -293,6 +293,76 @@ __global__ __launch_bounds__(kPrepBlock) void k_prep_deal(ml2048_state st, int64
     if (reset_indices) reset_indices[rank] = i;
 }
 
+// Small M (<= 16 boards per thread of one 1024-thread workgroup): the whole prepare in ONE launch.
+// Thread t owns the contiguous boards [t*B, (t+1)*B), so ranks are still in ascending slot order.
+template <bool FAST>
+__global__ __launch_bounds__(1024) void k_prep_small(ml2048_state st, int64_t M, int B, int64_t idx_base,
+                                                     const uint8_t *__restrict__ randperm,
+                                                     const float *__restrict__ randfloat, double two_prob,
+                                                     int64_t row_base, uint64_t seed, uint64_t counter, uint64_t thr,
+                                                     int32_t *__restrict__ game_count, int32_t *__restrict__ n_reset,
+                                                     int64_t *__restrict__ reset_indices) {
+    __shared__ int wave_tot[16];
+    uint32_t two_mask = 0;
+    if (!FAST) two_mask = two_mask_from_table(randfloat, two_prob);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t first = (int64_t)threadIdx.x * B;
+    uint32_t mine = 0; // bit j <=> board first+j is terminated
+    for (int j = 0; j < B; ++j) {
+        const int64_t i = first + j;
+        if (i < M && st.terminated[i] != 0) mine |= 1u << j;
+    }
+    const int cnt = __popc(mine);
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int n = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += n;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int base = incl - cnt, total = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) base += wave_tot[w];
+        total += wave_tot[w];
+    }
+    const int32_t gc0 = *game_count; // every thread reads it before the barrier below ...
+    __syncthreads();
+    if (threadIdx.x == 0) {          // ... and only then is it advanced
+        *n_reset = total;
+        *game_count = gc0 + total;
+    }
+    int rank = base;
+    for (int j = 0; j < B; ++j) {
+        if (!((mine >> j) & 1u)) continue;
+        const int64_t i = first + j;
+        StepRegs s;
+        clear_regs(s);
+        if (FAST) {
+            uint32_t w[4];
+            rocrand_words(seed, counter, (uint64_t)(idx_base + i), w);
+            spawn_counter(s.board, w[0], w[1], thr);
+            spawn_counter(s.board, w[2], w[3], thr);
+        } else {
+            uint32_t perm[4];
+            load_perm_row(randperm, row_base + idx_base + i, perm);
+            deal_table(s.board, perm, two_mask);
+        }
+        s.valid = valid_actions(s.board);
+        store16(st.board, i, s.board.r);
+        store16(st.merged, i, s.merged);
+        reinterpret_cast<uint32_t *>(st.valid)[i] = s.valid;
+        st.step[i] = 0;
+        st.score[i] = 0.0f;
+        st.reward[i] = 0.0f;
+        st.terminated[i] = 0;
+        st.invalid[i] = 0;
+        st.id[i] = gc0 + rank;
+        if (reset_indices) reset_indices[rank] = i;
+        ++rank;
+    }
+}
+
 // ---- sampler -------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_sample(const uint8_t *__restrict__ valid, int64_t M,
                                                    int64_t idx_base, uint64_t seed, uint64_t counter,
@@ -653,6 +723,49 @@ __global__ __launch_bounds__(kBlock) void k_ids_assign(ml2048_state st, int64_t 
     st.id[i] = gc0 + step_base[t] + rank;
 }
 
+// ---- transition record (run_train3.py:125-155) -------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_record(ml2048_state st, int64_t M, const uint8_t *__restrict__ actions,
+                                                   const float *__restrict__ logp, int8_t *__restrict__ o_state,
+                                                   uint8_t *__restrict__ o_valid, int8_t *__restrict__ o_action,
+                                                   float *__restrict__ o_logp, float *__restrict__ o_reward,
+                                                   int8_t *__restrict__ o_next_state, uint8_t *__restrict__ o_next_valid,
+                                                   int32_t *__restrict__ o_step, uint8_t *__restrict__ o_term) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= M) return;
+    if (o_state) reinterpret_cast<uint4 *>(o_state)[i] = reinterpret_cast<const uint4 *>(st.prev_board)[i];
+    if (o_next_state) reinterpret_cast<uint4 *>(o_next_state)[i] = reinterpret_cast<const uint4 *>(st.board)[i];
+    if (o_valid) reinterpret_cast<uint32_t *>(o_valid)[i] = reinterpret_cast<const uint32_t *>(st.prev_valid)[i];
+    if (o_next_valid) reinterpret_cast<uint32_t *>(o_next_valid)[i] = reinterpret_cast<const uint32_t *>(st.valid)[i];
+    if (o_reward) o_reward[i] = st.reward[i];
+    if (o_step) o_step[i] = st.step[i];
+    if (o_term) o_term[i] = st.terminated[i] != 0;
+    if (o_action && actions) o_action[i] = (int8_t)actions[i];
+    if (o_logp && logp) o_logp[i] = logp[i];
+}
+
+// ---- GAE scan (gae.py:50, :58-68) ---------------------------------------------------------------------
+// One lane per (use, game) pair walks the step dimension backwards; lanes of a wave are consecutive
+// games, so every access is a coalesced 256-byte row of the [U][S][G] tensors.
+__global__ __launch_bounds__(kBlock) void k_gae(int64_t U, int64_t S, int64_t G, const float *__restrict__ v0,
+                                                const float *__restrict__ v1, const float *__restrict__ reward,
+                                                const uint8_t *__restrict__ terminated, float gamma, float coef,
+                                                float *__restrict__ adv, float *__restrict__ delta_out) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= U * G) return;
+    const int64_t u = j / G, g = j - u * G;
+    float tmp = 0.0f;
+    for (int64_t s = S - 1; s >= 0; --s) {
+        const int64_t k = (u * S + s) * G + g;
+        const float mask = terminated[k] ? 0.0f : 1.0f;
+        // delta = gamma * v1 * mask + reward - v0, evaluated left to right in float32 (:50)
+        const float d = __fsub_rn(__fadd_rn(__fmul_rn(__fmul_rn(gamma, v1[k]), mask), reward[k]), v0[k]);
+        // tmp = tmp * coef; tmp = delta + tmp * mask (:66-67)
+        tmp = __fadd_rn(d, __fmul_rn(__fmul_rn(tmp, coef), mask));
+        adv[k] = tmp;
+        if (delta_out) delta_out[k] = d;
+    }
+}
+
 __global__ void k_snapshot(const int32_t *__restrict__ src, int32_t *__restrict__ dst) { *dst = *src; }
 
 uint64_t two_threshold(double two_prob) {
@@ -691,6 +804,12 @@ int launch_prepare(hipStream_t s, int64_t M, int64_t idx_base, const ml2048_stat
                    int64_t *reset_indices, int32_t *scratch) {
     if (!game_count || !n_reset || !scratch)
         return fail(ML2048_E_INVALID, "game_count, n_reset and scratch must be non-NULL");
+    if (M <= 16 * 1024) { // one workgroup does count + scan + deal
+        hipLaunchKernelGGL((k_prep_small<FAST>), dim3(1), dim3(1024), 0, s, *st, M, (int)cdiv(M, 1024), idx_base,
+                           randperm, randfloat, two_prob, row_base, seed, counter, two_threshold(two_prob),
+                           game_count, n_reset, reset_indices);
+        return check_launch("ml2048_prepare");
+    }
     const int nblk = (int)cdiv(M, kPrepBlock);
     hipLaunchKernelGGL(k_prep_count, dim3(nblk), dim3(kPrepBlock), 0, s, st->terminated, M, scratch);
     hipLaunchKernelGGL(k_prep_scan, dim3(1), dim3(1024), 0, s, scratch, nblk, game_count);
@@ -871,6 +990,33 @@ int ml2048_rollout_finish_ids(void *stream, int64_t M, const ml2048_state *st, i
     hipLaunchKernelGGL(k_ids_assign, dim3((unsigned)cdiv(M, kBlock)), dim3(kBlock), 0, s, *st, M, N, W, reset_flags,
                        last_reset, scratch, game_count, (int32_t)snap);
     return check_launch("ml2048_rollout_finish_ids");
+}
+
+int ml2048_record_transition(void *stream, int64_t M, const ml2048_state *st, const uint8_t *actions,
+                             const float *logp, int8_t *state, uint8_t *valid_actions, int8_t *action,
+                             float *action_log_prob, float *reward, int8_t *next_state, uint8_t *next_valid_actions,
+                             int32_t *step, uint8_t *terminated) {
+    if (int rc = check_state(M, st)) return rc;
+    if (((uintptr_t)state | (uintptr_t)next_state) % 16)
+        return fail(ML2048_E_ALIGN, "state/next_state slices must be 16-byte aligned");
+    if (((uintptr_t)valid_actions | (uintptr_t)next_valid_actions | (uintptr_t)reward | (uintptr_t)step |
+         (uintptr_t)action_log_prob) % 4)
+        return fail(ML2048_E_ALIGN, "4-byte outputs must be 4-byte aligned");
+    hipLaunchKernelGGL(k_record, dim3((unsigned)cdiv(M, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, *st, M, actions,
+                       logp, state, valid_actions, action, action_log_prob, reward, next_state, next_valid_actions, step,
+                       terminated);
+    return check_launch("ml2048_record_transition");
+}
+
+int ml2048_gae(void *stream, int64_t U, int64_t S, int64_t G, const float *v0, const float *v1, const float *reward,
+               const uint8_t *terminated, double gamma, double lambda_, float *adv, float *delta_out) {
+    if (U <= 0 || S <= 0 || G <= 0) return fail(ML2048_E_INVALID, "U=%lld S=%lld G=%lld must be positive",
+                                                  (long long)U, (long long)S, (long long)G);
+    if (!v0 || !v1 || !reward || !terminated || !adv) return fail(ML2048_E_INVALID, "v0/v1/reward/terminated/adv is NULL");
+    const float coef = (float)(gamma * lambda_); // `coef = gamma * lambda_` is a python float (gae.py:56)
+    hipLaunchKernelGGL(k_gae, dim3((unsigned)cdiv(U * G, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, U, S, G, v0, v1,
+                       reward, terminated, (float)gamma, coef, adv, delta_out);
+    return check_launch("ml2048_gae");
 }
 
 } // extern "C"

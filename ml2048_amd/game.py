@@ -129,6 +129,17 @@ class VecStepResult(TypedDict):  # game_numba.py:507-519
 _ACT_CODE = {torch.uint8: 0, torch.int32: 1, torch.int64: 2}
 
 
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL_CTX = _NullCtx()
+
+
 class VecGame:
     """Vectorized 2048 environment on one MI355X (see module docstring)."""
 
@@ -202,6 +213,12 @@ class VecGame:
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def _dev_ctx(self):
+        """Device guard only when the current device differs (the guard costs a few us per call)."""
+        if torch.cuda.current_device() == self.device.index:
+            return _NULL_CTX
+        return torch.cuda.device(self.device)
+
     def _st(self):
         return C.byref(self._state)
 
@@ -244,7 +261,7 @@ class VecGame:
 
     def records_torch(self) -> torch.Tensor:
         rec = torch.empty((self._size, 64), dtype=torch.uint8, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             _lib.check(self._L.ml2048_pack_records(self._stream(), self._size, self._st(), rec.data_ptr()), "pack_records")
         return rec
 
@@ -252,7 +269,7 @@ class VecGame:
         """Overwrite the device state from reference-layout records (tests / restoring a run)."""
         rec = np.ascontiguousarray(records).view(np.uint8).reshape(self._size, 64)
         dev = torch.from_numpy(rec).to(self.device)
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             _lib.check(self._L.ml2048_unpack_records(self._stream(), self._size, self._st(), dev.data_ptr()), "unpack_records")
 
     # ------------------------------------------------------------------------------------------
@@ -295,7 +312,7 @@ class VecGame:
         self._rng = HostRng(seed)
         self._fast_counter = 0
         self._upload_tables()
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             _lib.check(self._L.ml2048_reset(self._stream(), self._size, self._st()), "reset")
 
     def observations_torch(self) -> tuple[torch.Tensor, torch.Tensor]:
@@ -311,7 +328,7 @@ class VecGame:
         the first n_reset entries of the buffer are the ascending re-dealt slots."""
         L, M = self._L, self._size
         self._drop_prefetch()
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             if self._spawn == "table":
                 regen, row_base = self._rng.draw_prepare()  # :622-626, drawn unconditionally
                 if regen or self._tables_dirty:
@@ -352,7 +369,7 @@ class VecGame:
         a = self._as_device_actions(actions)
         L, M = self._L, self._size
         self._drop_prefetch()
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             if self._spawn == "table":
                 if self._tables_dirty:
                     self._upload_tables()
@@ -389,7 +406,7 @@ class VecGame:
         assert out.shape == (M, 16, 4, 4) and out.dtype == torch.float32 and out.is_contiguous()
         long = torch.empty((M, 16), dtype=torch.int64, device=self.device) if with_long else None
         bad = torch.zeros((1,), dtype=torch.int32, device=self.device) if check else None
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             _lib.check(self._L.ml2048_encode_onehot(
                 self._stream(), M, self.board.data_ptr(), out.data_ptr(),
                 long.data_ptr() if long is not None else None, bad.data_ptr() if bad is not None else None), "onehot")
@@ -401,7 +418,7 @@ class VecGame:
         """counts[max tile exponent] over all boards (or the terminated ones) added into `out`."""
         if out is None:
             out = torch.zeros((20,), dtype=torch.int32, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             _lib.check(self._L.ml2048_hist_maxcell(
                 self._stream(), self._size, self.board.data_ptr(),
                 self.terminated.data_ptr() if terminated_only else None, out.data_ptr()), "hist")
@@ -417,7 +434,7 @@ class VecGame:
 
     def digest(self, with_id: bool = True) -> int:
         out = torch.zeros((1,), dtype=torch.int64, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._dev_ctx():
             _lib.check(self._L.ml2048_digest(self._stream(), self._size, self._idx_base, self._st(), int(with_id),
                                              out.data_ptr()), "digest")
         return int(out.item()) & 0xFFFFFFFFFFFFFFFF
@@ -464,7 +481,7 @@ class VecGame:
         last = torch.empty((M,), dtype=torch.int32, device=dev)
         actions = torch.empty((N, M), dtype=torch.uint8, device=dev) if record_actions else None
         dig = torch.zeros((N,), dtype=torch.int64, device=dev) if digests else None
-        with torch.cuda.device(dev):
+        with self._dev_ctx():
             if kernel_events is not None:
                 kernel_events[0].record(torch.cuda.current_stream(dev))
             _lib.check(L.ml2048_rollout(

@@ -463,3 +463,27 @@ int64_t orc_prepare_fast(orc_record *data, int64_t M, int64_t idx_base, double t
     }
     return n;
 }
+
+/* gae.py:50, :58-68.  gamma and the python-float product gamma*lambda are each rounded once to
+ * float32 (torch's treatment of python scalars); every operation is a separate float32 op. */
+void orc_gae(int64_t U, int64_t S, int64_t G, const float *v0, const float *v1, const float *reward,
+             const uint8_t *terminated, double gamma, double lambda_, float *adv, float *delta_out) {
+    const float g = (float)gamma, coef = (float)(gamma * lambda_);
+    for (int64_t u = 0; u < U; ++u)
+        for (int64_t j = 0; j < G; ++j) {
+            float tmp = 0.0f;
+            for (int64_t s = S - 1; s >= 0; --s) {
+                const int64_t k = (u * S + s) * G + j;
+                const float mask = terminated[k] ? 0.0f : 1.0f;
+                volatile float a = g * v1[k];
+                volatile float b = a * mask;
+                volatile float c = b + reward[k];
+                const float d = c - v0[k];
+                volatile float e = tmp * coef;
+                volatile float f = e * mask;
+                tmp = d + f;
+                adv[k] = tmp;
+                if (delta_out) delta_out[k] = d;
+            }
+        }
+}

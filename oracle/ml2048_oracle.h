@@ -120,6 +120,11 @@ void orc_step_fast(orc_record *data, int64_t M, int64_t idx_base, const void *ac
 int64_t orc_prepare_fast(orc_record *data, int64_t M, int64_t idx_base, double two_prob,
                          uint64_t seed, uint64_t counter, int64_t *game_count, int64_t *indices);
 
+/* compute_gae's arithmetic, src/ml2048/gae.py:50 and :58-68, on [U][S][G] float32 tensors, in the
+ * reference's float32 operation order (compile with -ffp-contract=off). */
+void orc_gae(int64_t U, int64_t S, int64_t G, const float *v0, const float *v1, const float *reward,
+             const uint8_t *terminated, double gamma, double lambda_, float *adv, float *delta_out);
+
 #ifdef __cplusplus
 }
 #endif

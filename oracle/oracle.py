@@ -91,6 +91,7 @@ def _bind(L: C.CDLL) -> C.CDLL:
     L.orc_hist_maxcell.argtypes = [vp, i64, vp, i64, i64, vp]
     L.orc_philox4x32_10.argtypes = [vp, vp, vp]
     L.orc_sample_actions.argtypes = [vp, i64, i64, i64, u64, u64, i32, vp, vp]
+    L.orc_gae.argtypes = [i64, i64, i64, vp, vp, vp, vp, dbl, dbl, vp, vp]
     L.orc_digest.argtypes = [vp, i64, i64, i32]
     L.orc_digest.restype = u64
     L.orc_step_fast.argtypes = [vp, i64, i64, vp, i32, vp, vp, i32, dbl, u64, u64]
@@ -181,6 +182,19 @@ def hist_maxcell(board, terminated=None):
     t = None if terminated is None else np.ascontiguousarray(terminated, dtype=np.uint8)
     lib().orc_hist_maxcell(_p(board), 16, _p(t), 1, board.shape[0], _p(counts))
     return counts
+
+
+def gae(v0, v1, reward, terminated, gamma, lambda_):
+    """-> (adv, delta), float32 [U,S,G] (gae.py:50, :58-68)"""
+    v0 = np.ascontiguousarray(v0, np.float32)
+    v1 = np.ascontiguousarray(v1, np.float32)
+    reward = np.ascontiguousarray(reward, np.float32)
+    term = np.ascontiguousarray(terminated).astype(np.uint8)
+    U, S, G = v0.shape
+    adv = np.empty_like(v0)
+    delta = np.empty_like(v0)
+    lib().orc_gae(U, S, G, _p(v0), _p(v1), _p(reward), _p(term), float(gamma), float(lambda_), _p(adv), _p(delta))
+    return adv, delta
 
 
 # ---- host RNG schedule: game_numba.py:589-591, 606-611, 622-626, 670 -----------------------------
