@@ -50,6 +50,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary stepwise measurement")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for the barrier / max-over-ranks (nccl = RCCL; gloo only for "
+                         "rehearsing the N>1 launch contract on a box with fewer GPUs than ranks)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: map every rank to cuda:0 (needs --dist-backend gloo)")
     ap.add_argument("--prefetch", type=int, default=0,
                     help="draw the next rollout's host schedule on a worker thread (default 0: the async kernel "
                          "launch already overlaps the host schedule of rollout k+1 with the GPU running rollout k)")
@@ -147,6 +152,8 @@ def main():
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -154,7 +161,10 @@ def main():
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist_mod.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist_mod.init_process_group(backend="gloo")
         dist = dist_mod
 
     M, N, K, W = args.boards, args.env_steps, args.steps, args.warmup
