@@ -57,3 +57,28 @@ def test_two_prob_threshold_in_float64():
     assert r.two_mask(0.8) == 0 and r.two_mask(float(x) + 1e-12) == 0xFFFF
     _, _, masks = r.draw_schedule(1, 0.8)
     assert masks[0] == 0
+
+
+@pytest.mark.parametrize("threads,margin", [("1", "2500"), ("2", "0"), ("3", "40"), ("8", "0"), ("8", "2500"), ("16", "300")])
+def test_speculative_scan_is_exact_for_any_thread_count_and_overlap(threads, margin):
+    """The parallel row scan only guesses WHERE rows start; whatever the guesses and however little
+    the threads' segments overlap (margin 0 => the lists rarely coalesce and the serial continuation
+    takes over), the schedule must equal numpy's.  Run in a subprocess: the settings are read once."""
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np\n"
+        "from ml2048_amd.hostrng import HostRng\n"
+        "a, b = HostRng(77), HostRng(77)\n"
+        "for n in (128, 5, 700):\n"
+        "    s1, e1, m1 = a.draw_schedule(n, 0.8); s2, e2, m2 = b._draw_schedule_py(n, 0.8)\n"
+        "    assert np.array_equal(s1, s2) and np.array_equal(e1, e2) and np.array_equal(m1, m2)\n"
+        "    assert a.rand.bit_generator.state == b.rand.bit_generator.state\n"
+        "assert a.epoch > 60\n"
+        "print('ok')\n"
+    )
+    env = dict(os.environ, ML2048_HOST_THREADS=threads, ML2048_HOSTRNG_MARGIN=margin)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
