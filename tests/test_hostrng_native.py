@@ -78,7 +78,7 @@ def test_speculative_scan_is_exact_for_any_thread_count_and_overlap(threads, mar
         "assert a.epoch > 60\n"
         "print('ok')\n"
     )
-    env = dict(os.environ, ML2048_HOST_THREADS=threads, ML2048_HOSTRNG_MARGIN=margin)
+    env = dict(os.environ, ML2048_HOST_THREADS=threads, ML2048_HOSTRNG_MARGIN=margin, ML2048_HOSTRNG_SPEC="1")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
