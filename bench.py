@@ -47,6 +47,8 @@ def parse():
                          "obs: per-step API + masked sampling + one-hot (C3 pipeline)")
     ap.add_argument("--masked", type=int, default=0, help="masked-uniform actions (default: unmasked, C2)")
     ap.add_argument("--seed", type=int, default=20241008)
+    ap.add_argument("--step-mapping", choices=["lane", "wave"], default="lane",
+                    help="per-step kernel mapping: lane-per-board (default) or one wavefront per board")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary stepwise measurement")
@@ -169,7 +171,7 @@ def main():
 
     M, N, K, W = args.boards, args.env_steps, args.steps, args.warmup
     # shard `rank` of a 2-level game: independent replica with its own seed (SURVEY 8e replica mode)
-    env = amd.VecGame(M, amd.reward_fn_normal, device=dev, idx_base=0)
+    env = amd.VecGame(M, amd.reward_fn_normal, device=dev, idx_base=0, step_mapping=args.step_mapping)
     env.reset(args.seed + rank)
     pol = amd.RandomPolicy(seed=7 + rank, masked=bool(args.masked))
     obs = torch.empty((M, 16, 4, 4), dtype=torch.float32, device=dev) if args.mode == "obs" else None
@@ -239,7 +241,7 @@ def main():
         avg_ms = sorted(x.elapsed_time(y) for x, y in evs)[len(evs) // 2]
         per = BYTES_PER_BOARD_STEP
         achieved = per * M / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roofline = {"bound": "hbm", "kernel": "k_step" if args.step_mapping == "lane" else "k_step_wave", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_launch": per * M}
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")

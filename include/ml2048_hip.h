@@ -93,6 +93,15 @@ int ml2048_step(void *stream, int64_t M, int64_t idx_base, const ml2048_state *s
                 int64_t row_base, const uint8_t *randperm, const float *randfloat);
 
 /*
+ * ml2048_step with the one-wavefront-per-board mapping (board staged in LDS, 4 lanes own the 4
+ * lines, 16 lanes probe the spawn row, 8 lanes the movability tests).  Identical semantics and
+ * results; exists so that the two mappings can be measured against each other.
+ */
+int ml2048_step_wave(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st,
+                     const void *actions, int action_dtype, int reward_kind, double two_prob,
+                     int64_t row_base, const uint8_t *randperm, const float *randfloat);
+
+/*
  * Fast mode (no reference counterpart; NOT bit-exact with the numba path, statistically the same
  * game): the spawn uses rocRAND's Philox4x32-10 device generator keyed (seed; subsequence =
  * idx_base + idx; offset = 4 * counter) instead of the host PCG64 tables.  Cell = k-th empty cell,

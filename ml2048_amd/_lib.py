@@ -44,6 +44,8 @@ _SIGNATURES = {
                                  C.c_double, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ml2048_step": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_void_p, C.c_int, C.c_int,
                               C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ml2048_step_wave": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_void_p, C.c_int, C.c_int,
+                                   C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
     "ml2048_prepare_fast": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_double, C.c_uint64,
                                       C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ml2048_step_fast": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_void_p, C.c_int, C.c_int,

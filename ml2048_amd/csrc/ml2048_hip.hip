@@ -187,6 +187,128 @@ __global__ __launch_bounds__(kBlock) void k_step(ml2048_state st, int64_t M, int
     st.invalid[i] = 0;
 }
 
+// ---- step, wave-per-board variant ----------------------------------------------------------------------
+// The mapping BASELINE.json's north_star sketches: one wavefront per board, the board's 16 bytes
+// staged in LDS, 4 lanes each owning one line of the chosen direction, 16 lanes probing the
+// permutation row for the spawn, 8 lanes evaluating the 8 line-movability tests.  Same semantics and
+// bit-identical results as k_step; kept as a measured alternative: ~120 wave
+// instructions per board against ~10 per board for the lane-per-board kernel.
+__device__ __forceinline__ void line_movable_word(uint32_t x, bool &fwd, bool &bwd) {
+    const uint32_t n = x >> 8;                       // byte j = cell j+1
+    const uint32_t nzx = nz_bytes(x), zx = nzx ^ 0x80808080u;
+    const uint32_t eq = z_bytes(x ^ n);
+    fwd = ((nzx >> 8) & (zx | eq)) != 0;                                   // a cell can move toward 0
+    bwd = (nzx & (((zx >> 8) | 0x80000000u) | eq) & 0x00808080u) != 0;     // ... toward 3
+}
+
+__global__ __launch_bounds__(kBlock) void k_step_wave(ml2048_state st, int64_t M, int64_t idx_base,
+                                                      const void *__restrict__ actions, int action_dtype,
+                                                      int reward_kind, double two_prob, int64_t row_base,
+                                                      const uint8_t *__restrict__ randperm,
+                                                      const float *__restrict__ randfloat) {
+    __shared__ uint32_t lds[kBlock / 64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint8_t *B = reinterpret_cast<uint8_t *>(lds[wave]);
+    const uint32_t two_mask = two_mask_from_table(randfloat, two_prob);
+    const int64_t n_waves = (int64_t)gridDim.x * (kBlock / 64);
+    for (int64_t b = (int64_t)blockIdx.x * (kBlock / 64) + wave; b < M; b += n_waves) {
+        // ---- stage the board in LDS: lanes 0..3 carry one row word each (one 16-byte request)
+        uint32_t roww = 0;
+        if (lane < 4) {
+            roww = reinterpret_cast<const uint32_t *>(st.board)[b * 4 + lane];
+            lds[wave][lane] = roww;
+            reinterpret_cast<uint32_t *>(st.prev_board)[b * 4 + lane] = roww; // game_numba.py:672
+        }
+        const uint32_t valid = reinterpret_cast<const uint32_t *>(st.valid)[b]; // wave-uniform loads
+        const uint32_t action = load_action(actions, action_dtype, b);
+        if (lane == 0) reinterpret_cast<uint32_t *>(st.prev_valid)[b] = valid;  // :673
+        const bool ok = action < 4u && ((valid >> (8u * (action & 3u))) & 0xFFu) != 0u;
+        if (!ok) {
+            if (lane == 0) st.invalid[b] = 1; // :738
+            continue;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_wave_barrier(); // lgkmcnt(0): the row words are in LDS (same wave: no barrier)
+        Board prev;
+        prev.r[0] = lds[wave][0]; prev.r[1] = lds[wave][1]; prev.r[2] = lds[wave][2]; prev.r[3] = lds[wave][3];
+
+        // ---- move: lane j < 4 owns line j of the chosen direction (offset, stride) :93-122
+        uint32_t m = 0;
+        if (lane < 4) {
+            int off, stride;
+            switch (action) {
+            case 0: off = 4 * lane; stride = 1; break;
+            case 1: off = 4 * lane + 3; stride = -1; break;
+            case 2: off = lane; stride = 4; break;
+            default: off = 12 + lane; stride = -4; break;
+            }
+            uint32_t x = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x |= (uint32_t)B[off + r * stride] << (8 * r);
+            x = push_line(x, m);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) B[off + r * stride] = (uint8_t)(x >> (8 * r));
+        }
+        __builtin_amdgcn_wave_barrier();
+        // the <= 8 merge exponents, gathered from the four line owners
+        uint32_t mexp_first = 0, mexp_second = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t mj = __builtin_amdgcn_readlane(m, j);
+            mexp_first |= (mj & 0xFFu) << (8 * j);
+            mexp_second |= (mj >> 8) << (8 * j);
+        }
+        const MergeStats ms = merge_stats(mexp_first, mexp_second);
+        __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_wave_barrier();
+        Board cur;
+        cur.r[0] = lds[wave][0]; cur.r[1] = lds[wave][1]; cur.r[2] = lds[wave][2]; cur.r[3] = lds[wave][3];
+        const float reward = (float)reward_value(reward_kind, cur, prev, ms);
+
+        // ---- spawn: lanes 0..15 probe the permutation row in order (:198-210)
+        const uint4 pv = reinterpret_cast<const uint4 *>(randperm)[(row_base + idx_base + b) & (ML2048_RAND_SIZE - 1)];
+        const int q = (lane >> 2) & 3;
+        const uint32_t pw = q == 0 ? pv.x : q == 1 ? pv.y : q == 2 ? pv.z : pv.w;
+        const uint32_t c = ubfe(pw, 8u * (lane & 3), 4);
+        const bool empty_here = lane < 16 && B[c] == 0;
+        const unsigned long long hits = __ballot(empty_here);
+        if (hits) {
+            const int first = __builtin_ctzll(hits);
+            const uint32_t cell = __builtin_amdgcn_readlane(c, first);
+            if (lane == 0) B[cell] = (uint8_t)(2u - ubfe(two_mask, cell, 1));
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_wave_barrier();
+
+        // ---- mask: lanes 0..3 rows, lanes 4..7 columns (:259-289)
+        bool fwd = false, bwd = false;
+        if (lane < 8) {
+            const int off = lane < 4 ? 4 * lane : lane - 4, stride = lane < 4 ? 1 : 4;
+            uint32_t x = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x |= (uint32_t)B[off + r * stride] << (8 * r);
+            line_movable_word(x, fwd, bwd);
+        }
+        const unsigned long long fb = __ballot(fwd), bb = __ballot(bwd);
+        const uint32_t nv = ((fb & 0x0Full) ? 1u : 0u) | ((bb & 0x0Full) ? 0x100u : 0u) |
+                            ((fb & 0xF0ull) ? 0x10000u : 0u) | ((bb & 0xF0ull) ? 0x1000000u : 0u);
+
+        // ---- write back
+        if (lane < 4) {
+            reinterpret_cast<uint32_t *>(st.board)[b * 4 + lane] = lds[wave][lane];
+            const uint32_t mw = lane == 0 ? ms.merged[0] : lane == 1 ? ms.merged[1] : lane == 2 ? ms.merged[2] : ms.merged[3];
+            reinterpret_cast<uint32_t *>(st.merged)[b * 4 + lane] = mw;
+        }
+        if (lane == 0) {
+            reinterpret_cast<uint32_t *>(st.valid)[b] = nv;
+            st.step[b] = st.step[b] + 1;
+            st.score[b] = (float)((double)st.score[b] + (double)ms.sum_value);
+            st.reward[b] = reward;
+            st.terminated[b] = nv == 0u;
+            st.invalid[b] = 0;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_wave_barrier(); // LDS reads done before the next board overwrites the slot
+    }
+}
+
 // ---- prepare: count -> scan -> deal --------------------------------------------------------------
 // scratch layout: [0, nblk) per-block counts -> exclusive prefix; [nblk] total; [nblk+1] snapshot
 // of *game_count taken before any block of the deal kernel can advance it.
@@ -866,6 +988,22 @@ int ml2048_step(void *stream, int64_t M, int64_t idx_base, const ml2048_state *s
     if (row_base < 0 || idx_base < 0) return fail(ML2048_E_INVALID, "row_base/idx_base must be >= 0");
     return launch_step<false>((hipStream_t)stream, M, idx_base, st, actions, action_dtype, reward_kind, two_prob,
                               row_base, randperm, randfloat, 0, 0);
+}
+
+int ml2048_step_wave(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, const void *actions,
+                     int action_dtype, int reward_kind, double two_prob, int64_t row_base,
+                     const uint8_t *randperm, const float *randfloat) {
+    if (int rc = check_state(M, st)) return rc;
+    if (!actions || !randperm || !randfloat) return fail(ML2048_E_INVALID, "actions/randperm/randfloat is NULL");
+    if ((uintptr_t)randperm % 16) return fail(ML2048_E_ALIGN, "randperm must be 16-byte aligned");
+    if (action_dtype < 0 || action_dtype > 2) return fail(ML2048_E_INVALID, "action_dtype=%d", action_dtype);
+    if (reward_kind < 0 || reward_kind > 3) return fail(ML2048_E_INVALID, "reward_kind=%d", reward_kind);
+    if (row_base < 0 || idx_base < 0) return fail(ML2048_E_INVALID, "row_base/idx_base must be >= 0");
+    int64_t blocks = cdiv(M, kBlock / 64);
+    if (blocks > 256 * 8) blocks = 256 * 8; // 8 workgroups per CU, grid-stride over the boards
+    hipLaunchKernelGGL(k_step_wave, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, *st, M, idx_base,
+                       actions, action_dtype, reward_kind, two_prob, row_base, randperm, randfloat);
+    return check_launch("ml2048_step_wave");
 }
 
 int ml2048_step_fast(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, const void *actions,

@@ -157,6 +157,7 @@ class VecGame:
         spawn: str = "table",
         spawn_seed: Optional[int] = None,
         idx_base: int = 0,
+        step_mapping: str = "lane",
     ):
         if size <= 0:
             raise ValueError(f"size={size}")  # game_numba.py:561-562
@@ -177,6 +178,10 @@ class VecGame:
         self._reward_fn = reward_fn if reward_fn is not None else reward_fn_normal
         self._reward_kind = _reward_kind(reward_fn)
         self._spawn = spawn
+        if step_mapping not in ("lane", "wave"):
+            raise ValueError(f"step_mapping={step_mapping!r} (expected 'lane' or 'wave')")
+        # "wave" = the one-wavefront-per-board step kernel (same results; measured alternative)
+        self._step_fn = self._L.ml2048_step_wave if step_mapping == "wave" else self._L.ml2048_step
         self._spawn_seed = 0x2048 if spawn_seed is None else int(spawn_seed)
         self._idx_base = int(idx_base)
 
@@ -374,7 +379,7 @@ class VecGame:
                 if self._tables_dirty:
                     self._upload_tables()
                 row_base = self._rng.draw_step()  # :670
-                rc = L.ml2048_step(self._stream(), M, self._idx_base, self._st(), a.data_ptr(), _ACT_CODE[a.dtype],
+                rc = self._step_fn(self._stream(), M, self._idx_base, self._st(), a.data_ptr(), _ACT_CODE[a.dtype],
                                    self._reward_kind, self._two_prob, row_base, self._randperm_dev.data_ptr(),
                                    self._randfloat_dev.data_ptr())
             else:

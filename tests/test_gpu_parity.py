@@ -227,6 +227,34 @@ def test_high_exponent_boards_h9_h10(amd, oracle, torch_cuda):
         env.onehot(check=True)
 
 
+# ---- the one-wavefront-per-board step kernel (north_star's mapping) gives the same bits ------------------
+def test_wave_per_board_step_golden_c1(amd, golden_dir):
+    g = np.load(os.path.join(golden_dir, "rollout_c1.npz"))
+    env = amd.VecGame(1024, amd.reward_fn_normal, step_mapping="wave")
+    env.reset(12345)
+    for s in range(g["actions"].shape[0]):
+        env.prepare()
+        env.step(g["actions"][s])
+        assert _records_sha(env) == str(g["step_sha"][s]), f"step {s}"
+
+
+@pytest.mark.parametrize("M,kind", [(65536, "normal"), (1000, "improved"), (77, "maxcell"), (4096, "rank")])
+def test_wave_per_board_step_vs_oracle(amd, oracle, M, kind):
+    env = amd.VecGame(M, kind, step_mapping="wave")
+    ref = oracle.OracleVecGame(M, kind)
+    env.reset(20241008)
+    ref.reset(20241008)
+    pol = amd.RandomPolicy(seed=11, masked=False)
+    for s in range(100):
+        env.prepare_torch()
+        ref.prepare()
+        a, _ = pol.sample_actions_u8(env.valid_actions)
+        env.step_torch(a)
+        ref.step(a.cpu().numpy())
+        assert env.digest() == ref.digest(), s
+    _assert_same_state(env, ref)
+
+
 # ---- fused rollout ----------------------------------------------------------------------------------
 def _check_rollout(amd, oracle, M, N, seed, reward, masked):
     env = amd.VecGame(M, reward)

@@ -6,7 +6,9 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import ml2048_amd as amd
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
