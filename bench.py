@@ -280,6 +280,24 @@ def main():
                               "us_per_env_step": d1 / (N * reps) * 1e6,
                               "note": "per-step API: 5 kernel launches per env step (prepare x3, sample, step)"}
 
+    if rank == 0 and world == 1 and args.mode == "fused" and not args.no_extras:
+        # secondary: the same fused workload in rocRAND spawn mode (no host PCG64 schedule; statistically the same
+        # game, bit-exact with the oracle's counter-based spawn, NOT with numba) - purely GPU-bound
+        env3 = amd.VecGame(M, amd.reward_fn_normal, device=dev, spawn="rocrand", spawn_seed=args.seed)
+        env3.reset(args.seed)
+        for _ in range(3):
+            env3.rollout(N, masked=bool(args.masked), act_seed=7)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        reps = 50
+        for r in range(reps):
+            env3.rollout(N, masked=bool(args.masked), act_seed=7, act_counter=(r + 3) * N)
+        torch.cuda.synchronize(dev)
+        d1 = time.perf_counter() - t1
+        extras["rocrand_spawn_mode"] = {"value": M * N * reps / d1, "unit": "board-steps/s", "ms_per_step": d1 / reps * 1e3,
+                                        "note": "spawn='rocrand': fused rollout with the rocRAND Philox spawn, no host "
+                                                "schedule; not bit-exact with the numba path (see DESIGN.md)"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(M, N, args.seed, args.cpu_seconds)

@@ -214,6 +214,13 @@ int ml2048_rollout(void *stream, int64_t M, int64_t idx_base, const ml2048_state
                    const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed,
                    uint64_t act_counter0, uint8_t *actions_out, uint64_t *digests_out,
                    uint64_t *reset_flags, int32_t *last_reset);
+/* The same fused rollout in fast (rocRAND) spawn mode: no host schedule at all.  Equals N calls of
+ * ml2048_prepare_fast(counter = 2*(spawn_counter0+t)) / ml2048_sample_actions / ml2048_step_fast(
+ * counter = 2*(spawn_counter0+t)+1); bit-exact against the oracle's orc_*_fast, not against numba. */
+int ml2048_rollout_fast(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
+                        double two_prob, uint64_t spawn_seed, uint64_t spawn_counter0, int reward_kind,
+                        int masked, uint64_t act_seed, uint64_t act_counter0, uint8_t *actions_out,
+                        uint64_t *digests_out, uint64_t *reset_flags, int32_t *last_reset);
 /* ids for the boards dealt during a rollout + *game_count advanced by the total; step_resets:
  * device int32[N] out or NULL (boards dealt per step = len(prepare()[0]) of each step);
  * scratch: device int32[ml2048_rollout_scratch_ints(M, N)]. */

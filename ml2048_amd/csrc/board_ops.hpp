@@ -284,10 +284,16 @@ ML_HD void spawn_counter(Board &b, uint32_t a, uint32_t bword, uint64_t thr) {
     uint32_t n_empty = (uint32_t)__builtin_popcount(empties);
     if (n_empty == 0) return;
     uint32_t k = (uint32_t)(((uint64_t)a * n_empty) >> 32);
-    // k-th set bit: clear the k lowest set bits, then ctz
-    uint32_t m = empties;
-    for (uint32_t j = 0; j < k; ++j) m &= m - 1u;
-    uint32_t c = (uint32_t)__builtin_ctz(m);
+    // position of the k-th (0-based) set bit of the 16-bit mask, by branch-free halving
+    uint32_t m = empties, c = 0, cnt;
+    cnt = (uint32_t)__builtin_popcount(m & 0xFFu);
+    if (k >= cnt) { k -= cnt; c += 8; m >>= 8; }
+    cnt = (uint32_t)__builtin_popcount(m & 0xFu);
+    if (k >= cnt) { k -= cnt; c += 4; m >>= 4; }
+    cnt = (uint32_t)__builtin_popcount(m & 0x3u);
+    if (k >= cnt) { k -= cnt; c += 2; m >>= 2; }
+    cnt = m & 1u;
+    if (k >= cnt) c += 1;
     set_cell(b, c, ((uint64_t)bword < thr) ? 1u : 2u);
 }
 

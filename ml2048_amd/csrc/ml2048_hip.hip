@@ -660,7 +660,7 @@ __global__ __launch_bounds__(kBlock) void k_digest(ml2048_state st, int64_t M, i
 // Global traffic per step is the 16-byte permutation row(s) (L1/L2-resident 16 KiB table), the
 // optional 1-byte action, and 8 bytes of re-deal flags per wave; state is read once and written
 // once per launch.
-template <int KIND>
+template <int KIND, bool FAST>
 __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, int64_t idx_base, int N,
                                                     const uint8_t *__restrict__ perm_epochs,
                                                     const uint32_t *__restrict__ two_masks,
@@ -669,7 +669,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                                                     uint8_t *__restrict__ actions_out,
                                                     uint64_t *__restrict__ digests_out,
                                                     uint64_t *__restrict__ reset_flags, int64_t flag_words,
-                                                    int32_t *__restrict__ last_reset) {
+                                                    int32_t *__restrict__ last_reset, uint64_t spawn_seed,
+                                                    uint64_t spawn_counter0, uint64_t thr) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < M;
     const int64_t ii = live ? i : M - 1; // tail lanes shadow the last board (loads only, no stores)
@@ -698,11 +699,19 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
     uint32_t aw[4] = {0, 0, 0, 0}; // the sampler's current Philox block (4 consecutive steps)
 
     for (int t = 0; t < N; ++t) {
-        const int epoch = schedule[3 * t + 0];
-        const int64_t row_p = schedule[3 * t + 1];
-        const int64_t row_s = schedule[3 * t + 2];
-        const uint8_t *table = perm_epochs + (int64_t)epoch * (ML2048_RAND_SIZE * 16);
-        const uint32_t two_mask = two_masks[epoch];
+        // table mode: the pre-drawn host schedule; fast mode: rocRAND Philox words keyed
+        // (spawn_seed; board; 2*(counter0+t) for the deal, +1 for the step) as the per-step API does
+        int epoch = 0;
+        int64_t row_p = 0, row_s = 0;
+        const uint8_t *table = perm_epochs;
+        uint32_t two_mask = 0;
+        if (!FAST) {
+            epoch = schedule[3 * t + 0];
+            row_p = schedule[3 * t + 1];
+            row_s = schedule[3 * t + 2];
+            table = perm_epochs + (int64_t)epoch * (ML2048_RAND_SIZE * 16);
+            two_mask = two_masks[epoch];
+        }
 
         // ---- prepare (game_numba.py:619-658)
         const bool deal = s.terminated != 0;
@@ -713,9 +722,16 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
             invalid = 0;
             mexp_first = mexp_second = 0;
             merged_stale = true;
-            uint32_t perm[4];
-            load_perm_row(table, row_p + idx_base + ii, perm);
-            deal_table(s.board, perm, two_mask);
+            if (FAST) {
+                uint32_t w4[4];
+                rocrand_words(spawn_seed, 2ull * (spawn_counter0 + (uint64_t)t), (uint64_t)(idx_base + ii), w4);
+                spawn_counter(s.board, w4[0], w4[1], thr);
+                spawn_counter(s.board, w4[2], w4[3], thr);
+            } else {
+                uint32_t perm[4];
+                load_perm_row(table, row_p + idx_base + ii, perm);
+                deal_table(s.board, perm, two_mask);
+            }
             s.valid = valid_actions(s.board);
             last = t;
         }
@@ -737,9 +753,15 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
         prev_valid = s.valid;
         if (step_pre_lite(s, action, KIND, mexp_first, mexp_second)) {
             merged_stale = true;
-            uint32_t perm[4];
-            load_perm_row(table, row_s + idx_base + ii, perm);
-            spawn_table(s.board, perm, two_mask, 1);
+            if (FAST) {
+                uint32_t w4[4];
+                rocrand_words(spawn_seed, 2ull * (spawn_counter0 + (uint64_t)t) + 1ull, (uint64_t)(idx_base + ii), w4);
+                spawn_counter(s.board, w4[0], w4[1], thr);
+            } else {
+                uint32_t perm[4];
+                load_perm_row(table, row_s + idx_base + ii, perm);
+                spawn_table(s.board, perm, two_mask, 1);
+            }
             step_post(s);
             invalid = 0;
         } else {
@@ -1084,6 +1106,36 @@ int64_t ml2048_rollout_scratch_ints(int64_t M, int32_t N) {
     return (int64_t)N * ml2048_rollout_flag_words(M) + N + 2;
 }
 
+static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
+                          const uint8_t *perm_epochs, const uint32_t *two_masks, const int32_t *schedule,
+                          int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0, uint8_t *actions_out,
+                          uint64_t *digests_out, uint64_t *reset_flags, int32_t *last_reset, uint64_t spawn_seed,
+                          uint64_t spawn_counter0, double two_prob) {
+    const dim3 grid((unsigned)cdiv(M, kBlock)), block(kBlock);
+    const int64_t W = ml2048_rollout_flag_words(M);
+    const uint64_t thr = two_threshold(two_prob);
+#define ML_LAUNCH(K, F)                                                                                      \
+    hipLaunchKernelGGL((k_rollout<K, F>), grid, block, 0, s, *st, M, idx_base, N, perm_epochs, two_masks,   \
+                       schedule, masked, act_seed, act_counter0, actions_out, digests_out, reset_flags, W,  \
+                       last_reset, spawn_seed, spawn_counter0, thr)
+#define ML_KIND(F)                                                                   \
+    switch (reward_kind) {                                                           \
+    case ML2048_REWARD_NORMAL: ML_LAUNCH(REWARD_NORMAL, F); break;                   \
+    case ML2048_REWARD_IMPROVED: ML_LAUNCH(REWARD_IMPROVED, F); break;               \
+    case ML2048_REWARD_RANK: ML_LAUNCH(REWARD_RANK, F); break;                       \
+    case ML2048_REWARD_MAXCELL: ML_LAUNCH(REWARD_MAXCELL, F); break;                 \
+    default: return fail(ML2048_E_INVALID, "reward_kind=%d", reward_kind);           \
+    }
+    if (fast) {
+        ML_KIND(true)
+    } else {
+        ML_KIND(false)
+    }
+#undef ML_KIND
+#undef ML_LAUNCH
+    return check_launch("ml2048_rollout");
+}
+
 int ml2048_rollout(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
                    const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,
                    const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0,
@@ -1094,22 +1146,21 @@ int ml2048_rollout(void *stream, int64_t M, int64_t idx_base, const ml2048_state
         return fail(ML2048_E_INVALID, "perm_epochs/two_masks/schedule/reset_flags/last_reset is NULL");
     if ((uintptr_t)perm_epochs % 16) return fail(ML2048_E_ALIGN, "perm_epochs must be 16-byte aligned");
     if (idx_base < 0) return fail(ML2048_E_INVALID, "idx_base must be >= 0");
-    const dim3 grid((unsigned)cdiv(M, kBlock)), block(kBlock);
-    const int64_t W = ml2048_rollout_flag_words(M);
-    hipStream_t s = (hipStream_t)stream;
-#define ML_LAUNCH(K)                                                                                          \
-    hipLaunchKernelGGL((k_rollout<K>), grid, block, 0, s, *st, M, idx_base, N, perm_epochs, two_masks,       \
-                       schedule, masked, act_seed, act_counter0, actions_out, digests_out, reset_flags, W,  \
-                       last_reset)
-    switch (reward_kind) {
-    case ML2048_REWARD_NORMAL: ML_LAUNCH(REWARD_NORMAL); break;
-    case ML2048_REWARD_IMPROVED: ML_LAUNCH(REWARD_IMPROVED); break;
-    case ML2048_REWARD_RANK: ML_LAUNCH(REWARD_RANK); break;
-    case ML2048_REWARD_MAXCELL: ML_LAUNCH(REWARD_MAXCELL); break;
-    default: return fail(ML2048_E_INVALID, "reward_kind=%d", reward_kind);
-    }
-#undef ML_LAUNCH
-    return check_launch("ml2048_rollout");
+    return launch_rollout((hipStream_t)stream, false, M, idx_base, st, N, perm_epochs, two_masks, schedule, reward_kind,
+                          masked, act_seed, act_counter0, actions_out, digests_out, reset_flags, last_reset, 0, 0, 0.0);
+}
+
+int ml2048_rollout_fast(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
+                        double two_prob, uint64_t spawn_seed, uint64_t spawn_counter0, int reward_kind, int masked,
+                        uint64_t act_seed, uint64_t act_counter0, uint8_t *actions_out, uint64_t *digests_out,
+                        uint64_t *reset_flags, int32_t *last_reset) {
+    if (int rc = check_state(M, st)) return rc;
+    if (N <= 0) return fail(ML2048_E_INVALID, "N=%d must be positive", N);
+    if (!reset_flags || !last_reset) return fail(ML2048_E_INVALID, "reset_flags/last_reset is NULL");
+    if (idx_base < 0) return fail(ML2048_E_INVALID, "idx_base must be >= 0");
+    return launch_rollout((hipStream_t)stream, true, M, idx_base, st, N, nullptr, nullptr, nullptr, reward_kind, masked,
+                          act_seed, act_counter0, actions_out, digests_out, reset_flags, last_reset, spawn_seed,
+                          spawn_counter0, two_prob);
 }
 
 int ml2048_rollout_finish_ids(void *stream, int64_t M, const ml2048_state *st, int32_t N,

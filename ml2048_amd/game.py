@@ -449,7 +449,8 @@ class VecGame:
                 record_actions: bool = False, digests: bool = False, finish_ids: bool = True,
                 kernel_events: Optional[tuple] = None, prefetch_next: bool = False):
         """N x {prepare; uniform-random actions; step} fused into one kernel launch, bit-exact
-        with the per-step API on the same seeds (table spawn mode only).
+        with the per-step API on the same seeds (both spawn modes; spawn="rocrand" needs no host
+        schedule and is purely GPU-bound).
 
         Returns a dict: actions (N,M) uint8 | None, digests (N,) int64 (two's complement of the
         uint64) | None, step_resets (N,) int32 | None.
@@ -458,42 +459,50 @@ class VecGame:
         prefetch_next: draw the host schedule of the next rollout(n_steps) on a worker thread while
         this one runs on the GPU (results are identical either way).
         """
-        if self._spawn != "table":
-            raise ValueError("rollout() is defined for spawn='table'")
         N, M, dev = int(n_steps), self._size, self.device
         if N <= 0:
             raise ValueError(f"n_steps={n_steps}")
-        # the host schedule (independent of game state): one native call, or already drawn ahead
-        sched, epochs, masks = self._next_schedule(N)
-        # one packed H2D copy: [epoch tables | schedule | masks], each section 16-byte aligned
-        E = epochs.shape[0]
-        o_sched = E * RAND_SIZE * 16
-        o_mask = o_sched + ((N * 12 + 15) // 16) * 16
-        packed = np.empty((o_mask + E * 4,), dtype=np.uint8)
-        packed[:o_sched] = epochs.reshape(-1)
-        packed[o_sched:o_sched + N * 12] = sched.view(np.uint8).reshape(-1)
-        packed[o_mask:] = masks.view(np.uint8)
-        packed_dev = torch.from_numpy(packed).to(dev)
-        perm_dev = packed_dev[:o_sched]
-        sched_dev = packed_dev[o_sched:o_sched + N * 12]
-        mask_dev = packed_dev[o_mask:]
-        if E > 1:
-            self._tables_dirty = True  # device copies of the tables are refreshed lazily (per-step API)
-
         L = self._L
+        fast = self._spawn != "table"
+        if not fast:
+            # the host schedule (independent of game state): one native call, or already drawn ahead
+            sched, epochs, masks = self._next_schedule(N)
+            # one packed H2D copy: [epoch tables | schedule | masks], each section 16-byte aligned
+            E = epochs.shape[0]
+            o_sched = E * RAND_SIZE * 16
+            o_mask = o_sched + ((N * 12 + 15) // 16) * 16
+            packed = np.empty((o_mask + E * 4,), dtype=np.uint8)
+            packed[:o_sched] = epochs.reshape(-1)
+            packed[o_sched:o_sched + N * 12] = sched.view(np.uint8).reshape(-1)
+            packed[o_mask:] = masks.view(np.uint8)
+            packed_dev = torch.from_numpy(packed).to(dev)
+            perm_dev = packed_dev[:o_sched]
+            sched_dev = packed_dev[o_sched:o_sched + N * 12]
+            mask_dev = packed_dev[o_mask:]
+            if E > 1:
+                self._tables_dirty = True  # device copies of the tables are refreshed lazily (per-step API)
+
         W = int(L.ml2048_rollout_flag_words(M))
         flags = torch.empty((N, W), dtype=torch.int64, device=dev)
         last = torch.empty((M,), dtype=torch.int32, device=dev)
         actions = torch.empty((N, M), dtype=torch.uint8, device=dev) if record_actions else None
         dig = torch.zeros((N,), dtype=torch.int64, device=dev) if digests else None
+        a_ptr = actions.data_ptr() if actions is not None else None
+        d_ptr = dig.data_ptr() if dig is not None else None
         with self._dev_ctx():
             if kernel_events is not None:
                 kernel_events[0].record(torch.cuda.current_stream(dev))
-            _lib.check(L.ml2048_rollout(
-                self._stream(), M, self._idx_base, self._st(), N, perm_dev.data_ptr(), mask_dev.data_ptr(),
-                E, sched_dev.data_ptr(), self._reward_kind, int(masked), int(act_seed), int(act_counter),
-                actions.data_ptr() if actions is not None else None, dig.data_ptr() if dig is not None else None,
-                flags.data_ptr(), last.data_ptr()), "rollout")
+            if fast:  # rocRAND spawn: no host schedule at all
+                _lib.check(L.ml2048_rollout_fast(
+                    self._stream(), M, self._idx_base, self._st(), N, self._two_prob, self._spawn_seed,
+                    self._fast_counter, self._reward_kind, int(masked), int(act_seed), int(act_counter),
+                    a_ptr, d_ptr, flags.data_ptr(), last.data_ptr()), "rollout_fast")
+                self._fast_counter += N
+            else:
+                _lib.check(L.ml2048_rollout(
+                    self._stream(), M, self._idx_base, self._st(), N, perm_dev.data_ptr(), mask_dev.data_ptr(),
+                    E, sched_dev.data_ptr(), self._reward_kind, int(masked), int(act_seed), int(act_counter),
+                    a_ptr, d_ptr, flags.data_ptr(), last.data_ptr()), "rollout")
             if kernel_events is not None:
                 kernel_events[1].record(torch.cuda.current_stream(dev))
             step_resets = None

@@ -298,6 +298,34 @@ def test_rollout_small_cases(amd, oracle, M, N, masked, reward):
     _check_rollout(amd, oracle, M, N, 12345, reward, masked)
 
 
+def test_rollout_fast_mode_vs_oracle(amd, oracle):
+    """Fused rollout in rocRAND spawn mode == the oracle's counter-based spawn, step for step."""
+    M, N = 20000, 160
+    env = amd.VecGame(M, "improved", spawn="rocrand", spawn_seed=0x5EED)
+    ref = oracle.OracleVecGame(M, "improved", fast_seed=0x5EED)
+    env.reset(0)
+    ref.reset(0)
+    for part in range(2):  # two consecutive rollouts: the spawn counter carries over
+        out = env.rollout(N // 2, masked=True, act_seed=9, act_counter=part * (N // 2), record_actions=True,
+                          digests=True)
+        acts = out["actions"].cpu().numpy()
+        dig = out["digests"].cpu().numpy().view(np.uint64)
+        for s in range(N // 2):
+            (ridx,) = ref.prepare()
+            assert int(out["step_resets"][s].item()) == ridx.size
+            ref.step(acts[s])
+            assert int(dig[s]) == ref.digest(with_id=False), (part, s)
+    _assert_same_state(env, ref, "fast rollout")
+    assert env._game_count == ref._game_count > M
+    # and the per-step fast API continues from the same counters
+    env.prepare()
+    ref.prepare()
+    a = np.random.default_rng(1).integers(0, 4, size=M)
+    env.step(a)
+    ref.step(a)
+    _assert_same_state(env, ref, "fast step after fast rollout")
+
+
 def test_rollout_equals_stepwise_gpu(amd):
     """Same seeds -> the fused launch and N per-step launches leave identical device state."""
     M, N = 32768, 96
