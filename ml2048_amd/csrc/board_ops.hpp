@@ -254,16 +254,17 @@ ML_HD void spawn_table(Board &b, const uint32_t perm[4], uint32_t two_mask, int 
         const uint32_t c = ubfe(perm[i >> 2], 8u * (i & 3), 4);
         hits |= ubfe(empties, c, 1) << i;
     }
+    // NOTE: the chosen entry is extracted with 64-bit shifts, not by indexing perm[] with a runtime
+    // index (nor a select chain, which hipcc turns back into one): a runtime-indexed private array is
+    // promoted to LDS with a lane stride of 16 B and cost ~14 us per launch in k_step (measured).
+    const uint64_t plo = (uint64_t)perm[0] | ((uint64_t)perm[1] << 32);
+    const uint64_t phi = (uint64_t)perm[2] | ((uint64_t)perm[3] << 32);
     for (int n = 0; n < count; ++n) {
         if (hits == 0) break;
         const uint32_t i = (uint32_t)__builtin_ctz(hits);
         hits &= hits - 1u;
-        const uint32_t q = i >> 2;
-        uint32_t w = perm[0];
-        w = q == 1u ? perm[1] : w;
-        w = q == 2u ? perm[2] : w;
-        w = q == 3u ? perm[3] : w;
-        const uint32_t c = ubfe(w, 8u * (i & 3u), 4);
+        const uint64_t half = (i & 8u) ? phi : plo;
+        const uint32_t c = (uint32_t)(half >> (8u * (i & 7u))) & 0xFu;
         set_cell(b, c, 2u - ubfe(two_mask, c, 1));
     }
 }

@@ -99,10 +99,15 @@ __device__ __forceinline__ void rocrand_words(uint64_t seed, uint64_t counter, u
 
 // the action sampler's word for call-counter t: rocRAND's sequence of subsequence idx at offset t
 // (= word t&3 of Philox block t>>2; board_ops.hpp sampler_word)
+// (initialised at the block boundary t & ~3 and selected with a wave-uniform compare: starting
+// rocRAND at a non-multiple-of-4 offset makes its `result[substate]` a runtime-indexed private
+// array, which hipcc promotes to 16 KiB of LDS per workgroup - 17 us instead of 2.4 us per launch)
 __device__ __forceinline__ uint32_t rocrand_sampler_word(uint64_t seed, uint64_t t, uint64_t idx) {
     rocrand_state_philox4x32_10 s;
-    rocrand_init(seed, idx, t, &s);
-    return rocrand(&s);
+    rocrand_init(seed, idx, t & ~3ull, &s);
+    const uint4 v = rocrand4(&s);
+    const uint32_t k = (uint32_t)(t & 3ull); // wave-uniform
+    return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
 }
 
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
