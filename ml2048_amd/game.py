@@ -467,6 +467,10 @@ class VecGame:
         if not fast:
             # the host schedule (independent of game state): one native call, or already drawn ahead
             sched, epochs, masks = self._next_schedule(N)
+            if prefetch_next:
+                # start drawing the NEXT schedule right away: it then overlaps this call's packing,
+                # upload and launches as well as the GPU work
+                self._start_prefetch(N)
             # one packed H2D copy: [epoch tables | schedule | masks], each section 16-byte aligned
             E = epochs.shape[0]
             o_sched = E * RAND_SIZE * 16
@@ -514,7 +518,5 @@ class VecGame:
                     self._game_count_dev.data_ptr(), step_resets.data_ptr(), scratch.data_ptr()), "rollout_finish_ids")
         # every temporary above was allocated on the launch stream, so the caching allocator's
         # stream-ordered reuse keeps them valid until the kernels have consumed them
-        if prefetch_next:
-            self._start_prefetch(N)
         return {"actions": actions, "digests": dig, "step_resets": step_resets,
                 "reset_flags": flags, "last_reset": last}
