@@ -57,6 +57,8 @@ def parse():
                          "rehearsing the N>1 launch contract on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: map every rank to cuda:0 (needs --dist-backend gloo)")
+    ap.add_argument("--schedule", choices=["host", "device"], default="host",
+                    help="where the bit-exact mode's PCG64 draw schedule is computed (device: csrc/devrng.hip)")
     ap.add_argument("--prefetch", type=int, default=0,
                     help="draw the next rollout's host schedule on a worker thread (default 0: the async kernel "
                          "launch already overlaps the host schedule of rollout k+1 with the GPU running rollout k)")
@@ -171,7 +173,8 @@ def main():
 
     M, N, K, W = args.boards, args.env_steps, args.steps, args.warmup
     # shard `rank` of a 2-level game: independent replica with its own seed (SURVEY 8e replica mode)
-    env = amd.VecGame(M, amd.reward_fn_normal, device=dev, idx_base=0, step_mapping=args.step_mapping)
+    env = amd.VecGame(M, amd.reward_fn_normal, device=dev, idx_base=0, step_mapping=args.step_mapping,
+                      schedule=args.schedule)
     env.reset(args.seed + rank)
     pol = amd.RandomPolicy(seed=7 + rank, masked=bool(args.masked))
     obs = torch.empty((M, 16, 4, 4), dtype=torch.float32, device=dev) if args.mode == "obs" else None

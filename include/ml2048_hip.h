@@ -187,6 +187,29 @@ int ml2048_hostrng_schedule(ml2048_pcg64 *rng, uint8_t *randperm, float *randflo
                             uint32_t *two_masks, int32_t max_epochs, int32_t *n_epochs);
 
 /*
+ * The same schedule computed ON THE GPU (one 1024-thread workgroup; see csrc/devrng.hip), so that
+ * the bit-exact fused rollout needs no host work.  All pointers are DEVICE memory.
+ *   workspace  ml2048_devrng_workspace_bytes() bytes, filled once by ml2048_devrng_init
+ *   rng        the PCG64 state + VecGame._rand_step on the device, updated in place; rng->error is
+ *              set non-zero if max_epochs was too small or a regeneration window overflowed
+ *              (outputs are then invalid; the host path is the fallback)
+ *   randperm / randfloat  the device copies of the tables, regenerated in place
+ *   schedule, perm_epochs, two_masks, n_epochs  as ml2048_hostrng_schedule, in device memory
+ */
+typedef struct ml2048_devrng {
+    uint64_t state_hi, state_lo, inc_hi, inc_lo;
+    int32_t has_uint32;
+    uint32_t uinteger;
+    int32_t rand_step;
+    int32_t error;
+} ml2048_devrng;
+int64_t ml2048_devrng_workspace_bytes(void);
+int ml2048_devrng_init(void *stream, void *workspace);
+int ml2048_devrng_schedule(void *stream, const void *workspace, ml2048_devrng *rng, uint8_t *randperm,
+                           float *randfloat, int32_t n_steps, double two_prob, int32_t *schedule,
+                           uint8_t *perm_epochs, uint32_t *two_masks, int32_t max_epochs, int32_t *n_epochs);
+
+/*
  * Fused N-step rollout with on-device action sampling: the random-action loop
  *     for t in range(N): env.prepare(); a = policy.sample_actions(...); env.step(a)
  * (VecRunner.step_many with RandomPolicy, src/ml2048/runner.py:74-117, policy/random.py:17-27)

@@ -64,6 +64,10 @@ _SIGNATURES = {
     "ml2048_record_transition": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(State)] + [C.c_void_p] * 11),
     "ml2048_gae": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
+    "ml2048_devrng_workspace_bytes": (C.c_int64, []),
+    "ml2048_devrng_init": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ml2048_devrng_schedule": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "ml2048_rollout_flag_words": (C.c_int64, [C.c_int64]),
     "ml2048_rollout_scratch_ints": (C.c_int64, [C.c_int64, C.c_int32]),
     "ml2048_rollout": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_int32, C.c_void_p,

@@ -158,6 +158,7 @@ class VecGame:
         spawn_seed: Optional[int] = None,
         idx_base: int = 0,
         step_mapping: str = "lane",
+        schedule: str = "host",
     ):
         if size <= 0:
             raise ValueError(f"size={size}")  # game_numba.py:561-562
@@ -178,6 +179,12 @@ class VecGame:
         self._reward_fn = reward_fn if reward_fn is not None else reward_fn_normal
         self._reward_kind = _reward_kind(reward_fn)
         self._spawn = spawn
+        if schedule not in ("host", "device"):
+            raise ValueError(f"schedule={schedule!r} (expected 'host' or 'device')")
+        # where the PCG64 draw schedule of fused rollouts is computed: on the host (native, parallel)
+        # or by the single-workgroup GPU kernel of csrc/devrng.hip (no host work, same bits)
+        self._schedule_mode = schedule
+        self._rng_on_device = False  # True while the device copy of the generator is the current one
         if step_mapping not in ("lane", "wave"):
             raise ValueError(f"step_mapping={step_mapping!r} (expected 'lane' or 'wave')")
         # "wave" = the one-wavefront-per-board step kernel (same results; measured alternative)
@@ -212,6 +219,10 @@ class VecGame:
         self._scratch = torch.empty((int(self._L.ml2048_scratch_ints(M)),), dtype=i32, device=dev)
         self._hist = torch.zeros((20,), dtype=i32, device=dev)
         self._fast_counter = 0
+        self._devrng = torch.zeros((6,), dtype=torch.int64, device=dev)  # struct ml2048_devrng
+        self._devrng_ws = None
+        self._sched_stream = None
+        self._sched_slots = None
         self.reset()  # :584 (unseeded, as the reference constructor does)
 
     # ------------------------------------------------------------------------------------------
@@ -227,6 +238,46 @@ class VecGame:
     def _st(self):
         return C.byref(self._state)
 
+    # ---- host <-> device copies of the generator (schedule="device") ---------------------------
+    def _push_rng(self) -> None:
+        """Make the device generator current (before a device-side schedule)."""
+        if self._rng_on_device:
+            return
+        self._drop_prefetch()
+        st = self._rng.rand.bit_generator.state
+        s, inc = st["state"]["state"], st["state"]["inc"]
+        m64 = (1 << 64) - 1
+        words = np.zeros(6, dtype=np.uint64)
+        words[0], words[1], words[2], words[3] = s >> 64, s & m64, inc >> 64, inc & m64
+        words[4] = (int(st["has_uint32"]) & 0xFFFFFFFF) | ((int(st["uinteger"]) & 0xFFFFFFFF) << 32)
+        words[5] = self._rng.rand_step & 0xFFFFFFFF  # rand_step | error << 32
+        self._devrng.copy_(torch.from_numpy(words.view(np.int64)))
+        self._upload_tables()
+        # the schedule kernels run on a side stream: they must not start before these copies land
+        self._rng_push_event = torch.cuda.Event()
+        self._rng_push_event.record(torch.cuda.current_stream(self.device))
+        self._rng_on_device = True
+
+    def _pull_rng(self) -> None:
+        """Make the host generator current again (before any host-side draw or inspection)."""
+        if not self._rng_on_device:
+            return
+        words = self._devrng.cpu().numpy().view(np.uint64)
+        err = int(words[5] >> 32)
+        if err:
+            raise _lib.Ml2048Error(f"device schedule failed (code {err}): epoch buffer or word window too small")
+        bg = self._rng.rand.bit_generator
+        st = bg.state
+        st["state"]["state"] = (int(words[0]) << 64) | int(words[1])
+        st["has_uint32"] = int(words[4] & 0xFFFFFFFF)
+        st["uinteger"] = int(words[4] >> 32)
+        bg.state = st
+        self._rng.rand_step = int(words[5] & 0xFFFFFFFF)
+        self._rng.randperm[...] = self._randperm_dev.cpu().numpy()
+        self._rng.randfloat[...] = self._randfloat_dev.cpu().numpy()
+        self._tables_dirty = False
+        self._rng_on_device = False
+
     def _upload_tables(self) -> None:
         self._randperm_dev.copy_(torch.from_numpy(self._rng.randperm))
         self._randfloat_dev.copy_(torch.from_numpy(self._rng.randfloat))
@@ -236,14 +287,17 @@ class VecGame:
     @property
     def _rand_step(self) -> int:
         self._drop_prefetch()
+        self._pull_rng()
         return self._rng.rand_step
 
     @property
     def _randperm(self) -> np.ndarray:
+        self._pull_rng()
         return self._rng.randperm
 
     @property
     def _randfloat(self) -> np.ndarray:
+        self._pull_rng()
         return self._rng.randfloat
 
     @property
@@ -314,6 +368,7 @@ class VecGame:
     def reset(self, seed: Optional[int] = None) -> None:
         """game_numba.py:606-617.  `_game_count` is NOT reset (only the constructor sets it)."""
         self._drop_prefetch()
+        self._rng_on_device = False
         self._rng = HostRng(seed)
         self._fast_counter = 0
         self._upload_tables()
@@ -333,6 +388,7 @@ class VecGame:
         the first n_reset entries of the buffer are the ascending re-dealt slots."""
         L, M = self._L, self._size
         self._drop_prefetch()
+        self._pull_rng()
         with self._dev_ctx():
             if self._spawn == "table":
                 regen, row_base = self._rng.draw_prepare()  # :622-626, drawn unconditionally
@@ -374,6 +430,7 @@ class VecGame:
         a = self._as_device_actions(actions)
         L, M = self._L, self._size
         self._drop_prefetch()
+        self._pull_rng()
         with self._dev_ctx():
             if self._spawn == "table":
                 if self._tables_dirty:
@@ -445,6 +502,53 @@ class VecGame:
         return int(out.item()) & 0xFFFFFFFFFFFFFFFF
 
     # ------------------------------------------------------------------------------------------
+    def _device_schedule(self, N: int):
+        """Enqueue the GPU computation of the next N-step draw schedule (csrc/devrng.hip) and return
+        device views (perm_epochs, schedule, two_masks, max_epochs).  The schedule kernel runs on a
+        side stream, one slot ahead is possible: the rollout stream only waits for its own slot."""
+        L, dev = self._L, self.device
+        if self._devrng_ws is None:
+            self._devrng_ws = torch.empty((int(L.ml2048_devrng_workspace_bytes()),), dtype=torch.uint8, device=dev)
+            with self._dev_ctx():
+                _lib.check(L.ml2048_devrng_init(self._stream(), self._devrng_ws.data_ptr()), "devrng_init")
+        self._push_rng()
+        cap = N + 1  # one epoch per step at most: can never overflow
+        if self._sched_slots is None or self._sched_slots[0] != N:
+            slots = []
+            for _ in range(2):  # double-buffered outputs
+                slots.append({
+                    "perm": torch.empty((cap, RAND_SIZE, 16), dtype=torch.uint8, device=dev),
+                    "sched": torch.empty((N, 3), dtype=torch.int32, device=dev),
+                    "mask": torch.empty((cap,), dtype=torch.int32, device=dev),
+                    "ne": torch.zeros((1,), dtype=torch.int32, device=dev),
+                    "free": None,  # event: the rollout that consumed this slot has finished
+                })
+            self._sched_slots = (N, slots, 0)
+            if self._sched_stream is None:
+                self._sched_stream = torch.cuda.Stream(device=dev)
+            self._sched_stream.wait_stream(torch.cuda.current_stream(dev))  # workspace init, fresh buffers
+        _, slots, k = self._sched_slots
+        slot = slots[k]
+        self._sched_slots = (N, slots, k ^ 1)
+        main = torch.cuda.current_stream(dev)
+        side = self._sched_stream
+        if slot["free"] is not None:
+            side.wait_event(slot["free"])  # its previous consumer (two rollouts ago) has finished
+        push = getattr(self, "_rng_push_event", None)
+        if push is not None:
+            side.wait_event(push)
+            self._rng_push_event = None
+        with self._dev_ctx():
+            _lib.check(L.ml2048_devrng_schedule(
+                side.cuda_stream, self._devrng_ws.data_ptr(), self._devrng.data_ptr(), self._randperm_dev.data_ptr(),
+                self._randfloat_dev.data_ptr(), N, self._two_prob, slot["sched"].data_ptr(), slot["perm"].data_ptr(),
+                slot["mask"].data_ptr(), cap, slot["ne"].data_ptr()), "devrng_schedule")
+        ready = torch.cuda.Event()
+        ready.record(side)
+        main.wait_event(ready)
+        self._sched_pending_slot = slot
+        return slot["perm"], slot["sched"], slot["mask"], cap
+
     def rollout(self, n_steps: int, *, masked: bool = True, act_seed: int = 0, act_counter: int = 0,
                 record_actions: bool = False, digests: bool = False, finish_ids: bool = True,
                 kernel_events: Optional[tuple] = None, prefetch_next: bool = False):
@@ -464,7 +568,10 @@ class VecGame:
             raise ValueError(f"n_steps={n_steps}")
         L = self._L
         fast = self._spawn != "table"
-        if not fast:
+        on_device = (not fast) and self._schedule_mode == "device"
+        if on_device:
+            perm_dev, sched_dev, mask_dev, E = self._device_schedule(N)
+        elif not fast:
             # the host schedule (independent of game state): one native call, or already drawn ahead
             sched, epochs, masks = self._next_schedule(N)
             if prefetch_next:
@@ -507,6 +614,10 @@ class VecGame:
                     self._stream(), M, self._idx_base, self._st(), N, perm_dev.data_ptr(), mask_dev.data_ptr(),
                     E, sched_dev.data_ptr(), self._reward_kind, int(masked), int(act_seed), int(act_counter),
                     a_ptr, d_ptr, flags.data_ptr(), last.data_ptr()), "rollout")
+                if on_device:  # the slot may be overwritten once this rollout has consumed it
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(dev))
+                    self._sched_pending_slot["free"] = ev
             if kernel_events is not None:
                 kernel_events[1].record(torch.cuda.current_stream(dev))
             step_resets = None

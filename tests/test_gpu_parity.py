@@ -326,6 +326,54 @@ def test_rollout_fast_mode_vs_oracle(amd, oracle):
     _assert_same_state(env, ref, "fast step after fast rollout")
 
 
+# ---- the PCG64 draw schedule computed on the GPU (csrc/devrng.hip) --------------------------------------
+@pytest.mark.parametrize("seed", [0, 12345, 20241008, 987654321])
+def test_device_schedule_equals_host_schedule(amd, torch_cuda, seed):
+    """Schedule, epoch tables, 2/4 masks, final generator state, tables and rand_step: the device
+    kernel against the native host implementation (itself checked against numpy)."""
+    from ml2048_amd.hostrng import HostRng
+
+    env = amd.VecGame(64, schedule="device")
+    env.reset(seed)
+    ref = HostRng(seed)
+    for n in (128, 1, 7, 300, 128, 1100):
+        perm, sched, mask, cap = env._device_schedule(n)
+        torch_cuda.cuda.synchronize()
+        ne = int(env._sched_pending_slot["ne"].item())
+        s2, e2, m2 = ref.draw_schedule(n, 0.8)
+        assert ne == e2.shape[0], (seed, n)
+        assert np.array_equal(sched.cpu().numpy(), s2), (seed, n)
+        assert np.array_equal(perm[:ne].cpu().numpy(), e2), (seed, n)
+        assert np.array_equal(mask[:ne].cpu().numpy().view(np.uint32), m2), (seed, n)
+    assert env._rand_step == ref.rand_step  # pulls the device generator back to the host
+    assert np.array_equal(env._randperm, ref.randperm) and np.array_equal(env._randfloat, ref.randfloat)
+    assert env._rng.rand.bit_generator.state == ref.rand.bit_generator.state
+    assert env._rng.rand.random() == ref.rand.random()
+
+
+def test_device_schedule_rollouts_equal_host_schedule_rollouts(amd):
+    """Fused rollouts with the schedule drawn on the GPU leave exactly the state that host-drawn
+    ones do, and the per-step API continues from it."""
+    M = 8192
+    a = amd.VecGame(M, "improved", schedule="device")
+    b = amd.VecGame(M, "improved", schedule="host")
+    a.reset(31)
+    b.reset(31)
+    for k, n in enumerate((128, 64, 128, 200)):
+        a.rollout(n, masked=True, act_seed=2, act_counter=1000 * k)
+        b.rollout(n, masked=True, act_seed=2, act_counter=1000 * k)
+    assert a._data.tobytes() == b._data.tobytes()
+    assert a._game_count == b._game_count and a._rand_step == b._rand_step
+    act = np.random.default_rng(5).integers(0, 4, size=M)
+    for env in (a, b):
+        env.prepare()
+        env.step(act)
+    assert a._data.tobytes() == b._data.tobytes()
+    a.rollout(50)  # and back to the device schedule after host-side draws
+    b.rollout(50)
+    assert a.digest() == b.digest()
+
+
 def test_rollout_equals_stepwise_gpu(amd):
     """Same seeds -> the fused launch and N per-step launches leave identical device state."""
     M, N = 32768, 96
