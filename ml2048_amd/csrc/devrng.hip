@@ -134,6 +134,14 @@ __global__ __launch_bounds__(kThreads) void k_devrng_schedule(const Jump *__rest
     }
     int E = 1;
     __syncthreads();
+#ifdef ML2048_DEVRNG_STATS
+    long long t_gen = 0, t_relax = 0, t_rows = 0, t_replay = 0, t_float = 0, sweeps = 0, t_all = clock64();
+#define ML_T0 long long _t0 = clock64();
+#define ML_T(acc) { long long _t1 = clock64(); acc += _t1 - _t0; _t0 = _t1; }
+#else
+#define ML_T0
+#define ML_T(acc)
+#endif
 
     const uint64_t kNine = 8106479329266893ull; // u >= 0.9  <=>  (out >> 11) >= 0.9 * 2^53 (exact)
 
@@ -148,6 +156,7 @@ __global__ __launch_bounds__(kThreads) void k_devrng_schedule(const Jump *__rest
                 err = 1;
                 break;
             }
+            ML_T0
             // (1) the word window: [pending half] + halves of the next kThreads*12 outputs
             const int p0 = has32 ? 1 : 0;
             if (p0 && t == 0) nib[0] = (uint8_t)(buf32 & 15u);
@@ -164,28 +173,41 @@ __global__ __launch_bounds__(kThreads) void k_devrng_schedule(const Jump *__rest
             }
             seg_state[t] = 15;
             __syncthreads();
-            // (2) relaxation: state at the start of my segment
-            const uint8_t *seg = nib + kSeg * t;
+            ML_T(t_gen)
+            // (2) relaxation: state at the start of my segment.  The acceptance bitmaps of my 24
+            //     words are loaded once (they do not depend on the state), so a sweep is a pure ALU
+            //     chain: i -= (bits_k >> i) & 1 - no LDS latency inside it.
+            uint32_t accw[kSeg / 2]; // two 16-bit bitmaps per register
+            {
+                const uint8_t *seg = nib + kSeg * t;
+#pragma unroll
+                for (int k = 0; k < kSeg; k += 2)
+                    accw[k / 2] = (uint32_t)acc_tab[seg[k]] | ((uint32_t)acc_tab[seg[k + 1]] << 16);
+            }
             for (;;) {
                 int i = seg_state[t];
-#pragma unroll 8
+#pragma unroll
                 for (int k = 0; k < kSeg; ++k) {
-                    i -= (acc_tab[seg[k]] >> i) & 1;
+                    i -= (accw[k / 2] >> (16 * (k & 1) + i)) & 1;
                     i = i == 0 ? 15 : i;
                 }
                 const int nxt = t + 1 < kThreads ? seg_state[t + 1] : i;
                 const int changed = (t + 1 < kThreads) && nxt != i;
                 __syncthreads();
                 if (changed) seg_state[t + 1] = (uint8_t)i;
+#ifdef ML2048_DEVRNG_STATS
+                ++sweeps;
+#endif
                 if (!__syncthreads_or(changed)) break;
             }
+            ML_T(t_relax)
             // (3) number the rows: completions per segment -> exclusive scan -> row starts
             int cnt = 0;
             {
                 int i = seg_state[t];
-#pragma unroll 8
+#pragma unroll
                 for (int k = 0; k < kSeg; ++k) {
-                    i -= (acc_tab[seg[k]] >> i) & 1;
+                    i -= (accw[k / 2] >> (16 * (k & 1) + i)) & 1;
                     if (i == 0) {
                         i = 15;
                         ++cnt;
@@ -205,8 +227,9 @@ __global__ __launch_bounds__(kThreads) void k_devrng_schedule(const Jump *__rest
             if (t == 0) row_start[0] = 0;
             {
                 int i = seg_state[t], done = before;
+#pragma unroll
                 for (int k = 0; k < kSeg; ++k) {
-                    i -= (acc_tab[seg[k]] >> i) & 1;
+                    i -= (accw[k / 2] >> (16 * (k & 1) + i)) & 1;
                     if (i == 0) {
                         i = 15;
                         ++done; // row (done-1) just completed; row `done` starts at the next word
@@ -217,15 +240,19 @@ __global__ __launch_bounds__(kThreads) void k_devrng_schedule(const Jump *__rest
             __syncthreads();
             int total_rows = 0;
             for (int w = 0; w < kThreads / 64; ++w) total_rows += scan_tmp[w];
+            // LDS values are per-lane to the compiler; these are wave-uniform by construction, and
+            // saying so keeps the whole generator cursor (128-bit math) on the scalar unit
+            total_rows = __builtin_amdgcn_readfirstlane(total_rows);
             if (total_rows < kThreads) { // the window did not cover 1024 rows (never in practice)
                 err = 2;
                 break;
             }
-            const uint32_t used = row_start[kThreads]; // words consumed by the 1024 rows
+            const uint32_t used = (uint32_t)__builtin_amdgcn_readfirstlane((int)row_start[kThreads]); // words consumed by the 1024 rows
             if (used + ML2048_RAND_SIZE > (uint32_t)kWords) {
                 err = 2;
                 break;
             }
+            ML_T(t_rows)
             // (4) replay my row and apply its swaps (Generator.permuted, i = 15..1)
             {
                 uint32_t pos = row_start[t];
@@ -246,6 +273,8 @@ __global__ __launch_bounds__(kThreads) void k_devrng_schedule(const Jump *__rest
                 for (int q = 0; q < 16; ++q) w[q >> 2] |= (uint32_t)rows[q][t] << (8 * (q & 3));
                 reinterpret_cast<uint4 *>(perm_epochs)[(size_t)E * kThreads + t] = make_uint4(w[0], w[1], w[2], w[3]);
             }
+            __syncthreads();
+            ML_T(t_replay)
             // (5) Generator.random(float32): word used+t of the window; needs the full 32 bits, so
             //     the output is recomputed: W[k] (k >= p0) = half (k-p0)&1 of LCG step (k-p0)/2 + 1
             {
@@ -282,6 +311,7 @@ __global__ __launch_bounds__(kThreads) void k_devrng_schedule(const Jump *__rest
             }
             ++E;
             __syncthreads();
+            ML_T(t_float)
         }
         // rand_offset of prepare (:626) and of step (:670): integers(0, 1024) = next32 >> 22
         uint32_t w1, w2;
@@ -328,6 +358,11 @@ __global__ __launch_bounds__(kThreads) void k_devrng_schedule(const Jump *__rest
         rng->rand_step = rs;
         rng->error = err;
         *n_epochs = E;
+#ifdef ML2048_DEVRNG_STATS
+        long long *dbg = reinterpret_cast<long long *>(n_epochs + 2);
+        dbg[0] = sweeps; dbg[1] = t_gen; dbg[2] = t_relax; dbg[3] = t_rows; dbg[4] = t_replay; dbg[5] = t_float;
+        dbg[6] = clock64() - t_all;
+#endif
     }
 }
 

@@ -676,6 +676,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                                                     uint64_t *__restrict__ reset_flags, int64_t flag_words,
                                                     int32_t *__restrict__ last_reset, uint64_t spawn_seed,
                                                     uint64_t spawn_counter0, uint64_t thr) {
+    // The schedule kernel of the NEXT rollout (csrc/devrng.hip) may share a CU with one of these
+    // workgroups; the rollout is the critical path, so its waves win the issue arbitration.
+    __builtin_amdgcn_s_setprio(1);
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < M;
     const int64_t ii = live ? i : M - 1; // tail lanes shadow the last board (loads only, no stores)
