@@ -186,6 +186,10 @@ int ml2048_hostrng_schedule(ml2048_pcg64 *rng, uint8_t *randperm, float *randflo
                             int32_t n_steps, double two_prob, int32_t *schedule, uint8_t *perm_epochs,
                             uint32_t *two_masks, int32_t max_epochs, int32_t *n_epochs);
 
+/* One table regeneration (`VecGame._reset_rand`, game_numba.py:589-591: permuted(axis=1) in place +
+ * random(float32)) on the given generator state and HOST tables, as numpy would perform it. */
+int ml2048_hostrng_regen(ml2048_pcg64 *rng, uint8_t *randperm, float *randfloat);
+
 /*
  * The same schedule computed ON THE GPU (one 1024-thread workgroup; see csrc/devrng.hip), so that
  * the bit-exact fused rollout needs no host work.  All pointers are DEVICE memory.

@@ -64,6 +64,7 @@ _SIGNATURES = {
     "ml2048_record_transition": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(State)] + [C.c_void_p] * 11),
     "ml2048_gae": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
+    "ml2048_hostrng_regen": (C.c_int, [C.POINTER(Pcg64State), C.c_void_p, C.c_void_p]),
     "ml2048_devrng_workspace_bytes": (C.c_int64, []),
     "ml2048_devrng_init": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ml2048_devrng_schedule": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,

@@ -227,7 +227,11 @@ class VecGame:
 
     # ------------------------------------------------------------------------------------------
     def _stream(self) -> int:
-        return torch.cuda.current_stream(self.device).cuda_stream
+        """hipStream_t of torch's current stream on this device (raw accessor: ~0.3 us vs ~4 us)."""
+        try:
+            return torch._C._cuda_getCurrentRawStream(self.device.index)
+        except AttributeError:  # pragma: no cover - older/newer torch without the raw accessor
+            return torch.cuda.current_stream(self.device).cuda_stream
 
     def _dev_ctx(self):
         """Device guard only when the current device differs (the guard costs a few us per call)."""

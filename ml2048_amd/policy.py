@@ -7,6 +7,17 @@ import torch
 from . import _lib
 
 
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
 class Policy:
     def sample_actions(self, state, valid_actions, *, generator=None):
         raise NotImplementedError
@@ -34,8 +45,13 @@ class RandomPolicy(Policy):
         M = v.shape[0]
         actions = torch.empty((M,), dtype=torch.uint8, device=v.device)
         logp = torch.empty((M,), dtype=torch.float32, device=v.device)
-        with torch.cuda.device(v.device):
+        idx = v.device.index if v.device.index is not None else torch.cuda.current_device()
+        try:
+            stream = torch._C._cuda_getCurrentRawStream(idx)
+        except AttributeError:  # pragma: no cover
             stream = torch.cuda.current_stream(v.device).cuda_stream
+        guard = torch.cuda.device(idx) if torch.cuda.current_device() != idx else _NO_GUARD
+        with guard:
             _lib.check(self._L.ml2048_sample_actions(stream, M, self.idx_base, v.data_ptr(), self.seed, self.counter,
                                                      int(self.masked), actions.data_ptr(), logp.data_ptr()), "sample")
         self.counter += 1
