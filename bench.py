@@ -57,8 +57,9 @@ def parse():
                          "rehearsing the N>1 launch contract on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: map every rank to cuda:0 (needs --dist-backend gloo)")
-    ap.add_argument("--schedule", choices=["host", "device"], default="host",
-                    help="where the bit-exact mode's PCG64 draw schedule is computed (device: csrc/devrng.hip)")
+    ap.add_argument("--schedule", choices=["host", "host-async", "device"], default="host-async",
+                    help="where the bit-exact mode's PCG64 draw schedule is computed: host (synchronous native call), "
+                         "host-async (native producer thread drawing ahead; default), device (csrc/devrng.hip)")
     ap.add_argument("--prefetch", type=int, default=0,
                     help="draw the next rollout's host schedule on a worker thread (default 0: the async kernel "
                          "launch already overlaps the host schedule of rollout k+1 with the GPU running rollout k)")

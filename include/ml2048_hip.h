@@ -186,6 +186,25 @@ int ml2048_hostrng_schedule(ml2048_pcg64 *rng, uint8_t *randperm, float *randflo
                             int32_t n_steps, double two_prob, int32_t *schedule, uint8_t *perm_epochs,
                             uint32_t *two_masks, int32_t max_epochs, int32_t *n_epochs);
 
+/*
+ * Asynchronous form of ml2048_hostrng_schedule: a producer thread owned by the stream keeps `depth`
+ * n_steps-schedules drawn ahead (the only entry points that own memory / a thread; explicit
+ * create/destroy).  next() blocks until the oldest undelivered schedule is ready and returns pointers
+ * into its slot, valid until release(); rng_after / rand_step_after / randperm_after /
+ * randfloat_after are the generator, counter and tables exactly after that schedule, so the caller
+ * can re-synchronise its own generator to what it has consumed and discard the rest by destroy().
+ */
+typedef struct ml2048_sched_stream ml2048_sched_stream;
+ml2048_sched_stream *ml2048_sched_stream_create(const ml2048_pcg64 *rng, const uint8_t *randperm,
+                                                const float *randfloat, int32_t rand_step, int32_t n_steps,
+                                                double two_prob, int32_t depth);
+int ml2048_sched_stream_next(ml2048_sched_stream *s, const int32_t **schedule, const uint8_t **perm_epochs,
+                             const uint32_t **two_masks, int32_t *n_epochs, ml2048_pcg64 *rng_after,
+                             int32_t *rand_step_after, const uint8_t **randperm_after,
+                             const float **randfloat_after);
+int ml2048_sched_stream_release(ml2048_sched_stream *s);
+void ml2048_sched_stream_destroy(ml2048_sched_stream *s);
+
 /* One table regeneration (`VecGame._reset_rand`, game_numba.py:589-591: permuted(axis=1) in place +
  * random(float32)) on the given generator state and HOST tables, as numpy would perform it. */
 int ml2048_hostrng_regen(ml2048_pcg64 *rng, uint8_t *randperm, float *randfloat);

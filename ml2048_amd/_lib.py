@@ -64,6 +64,13 @@ _SIGNATURES = {
     "ml2048_record_transition": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(State)] + [C.c_void_p] * 11),
     "ml2048_gae": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
+    "ml2048_sched_stream_create": (C.c_void_p, [C.POINTER(Pcg64State), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                               C.c_double, C.c_int32]),
+    "ml2048_sched_stream_next": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                           C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(Pcg64State),
+                                           C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "ml2048_sched_stream_release": (C.c_int, [C.c_void_p]),
+    "ml2048_sched_stream_destroy": (None, [C.c_void_p]),
     "ml2048_hostrng_regen": (C.c_int, [C.POINTER(Pcg64State), C.c_void_p, C.c_void_p]),
     "ml2048_devrng_workspace_bytes": (C.c_int64, []),
     "ml2048_devrng_init": (C.c_int, [C.c_void_p, C.c_void_p]),

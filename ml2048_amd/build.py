@@ -34,7 +34,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     for src in HOST_SOURCES:
         obj = os.path.splitext(src)[0] + ".o"
-        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-fopenmp", "-c", src, "-o", obj]
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-fopenmp", "-pthread", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -46,7 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH, *objs, "-lgomp"]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH, *objs, "-lgomp", "-lpthread"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

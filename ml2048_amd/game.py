@@ -179,11 +179,15 @@ class VecGame:
         self._reward_fn = reward_fn if reward_fn is not None else reward_fn_normal
         self._reward_kind = _reward_kind(reward_fn)
         self._spawn = spawn
-        if schedule not in ("host", "device"):
-            raise ValueError(f"schedule={schedule!r} (expected 'host' or 'device')")
+        if schedule not in ("host", "host-async", "device"):
+            raise ValueError(f"schedule={schedule!r} (expected 'host', 'host-async' or 'device')")
         # where the PCG64 draw schedule of fused rollouts is computed: on the host (native, parallel)
         # or by the single-workgroup GPU kernel of csrc/devrng.hip (no host work, same bits)
+        # "host-async": a native producer thread keeps the next schedules drawn ahead (no GIL involved)
         self._schedule_mode = schedule
+        self._sstream = None        # ml2048_sched_stream handle
+        self._sstream_n = 0
+        self._sstream_after = None  # generator / counter / tables after the last CONSUMED schedule
         self._rng_on_device = False  # True while the device copy of the generator is the current one
         if step_mapping not in ("lane", "wave"):
             raise ValueError(f"step_mapping={step_mapping!r} (expected 'lane' or 'wave')")
@@ -242,12 +246,21 @@ class VecGame:
     def _st(self):
         return C.byref(self._state)
 
+    def __del__(self):  # stop the producer thread of an open schedule stream
+        try:
+            if getattr(self, "_sstream", None) is not None:
+                self._L.ml2048_sched_stream_destroy(self._sstream)
+                self._sstream = None
+        except Exception:
+            pass
+
     # ---- host <-> device copies of the generator (schedule="device") ---------------------------
     def _push_rng(self) -> None:
         """Make the device generator current (before a device-side schedule)."""
         if self._rng_on_device:
             return
         self._drop_prefetch()
+        self._close_sched_stream()
         st = self._rng.rand.bit_generator.state
         s, inc = st["state"]["state"], st["state"]["inc"]
         m64 = (1 << 64) - 1
@@ -262,8 +275,65 @@ class VecGame:
         self._rng_push_event.record(torch.cuda.current_stream(self.device))
         self._rng_on_device = True
 
+    # ---- asynchronous host schedule stream (schedule="host-async") ------------------------------
+    def _close_sched_stream(self) -> None:
+        """Stop the producer thread and bring self._rng to exactly what has been consumed."""
+        if self._sstream is None:
+            return
+        self._L.ml2048_sched_stream_destroy(self._sstream)
+        self._sstream = None
+        after = self._sstream_after
+        self._sstream_after = None
+        if after is not None:
+            c, rand_step, perm, flt = after
+            bg = self._rng.rand.bit_generator
+            st = bg.state
+            st["state"]["state"] = (int(c.state_hi) << 64) | int(c.state_lo)
+            st["has_uint32"] = int(c.has_uint32)
+            st["uinteger"] = int(c.uinteger)
+            bg.state = st
+            self._rng.rand_step = int(rand_step)
+            self._rng.randperm[...] = perm
+            self._rng.randfloat[...] = flt
+            self._tables_dirty = True
+
+    def _next_schedule_async(self, N: int):
+        L = self._L
+        if self._sstream is not None and self._sstream_n != N:
+            self._close_sched_stream()
+        if self._sstream is None:
+            self._drop_prefetch()
+            st = self._rng.rand.bit_generator.state
+            s, inc = st["state"]["state"], st["state"]["inc"]
+            m64 = (1 << 64) - 1
+            c = _lib.Pcg64State(s >> 64, s & m64, inc >> 64, inc & m64, int(st["has_uint32"]), int(st["uinteger"]))
+            self._sstream = L.ml2048_sched_stream_create(C.byref(c), self._rng.randperm.ctypes.data,
+                                                         self._rng.randfloat.ctypes.data, self._rng.rand_step, N,
+                                                         self._two_prob, 3)
+            if not self._sstream:
+                raise _lib.Ml2048Error("ml2048_sched_stream_create failed")
+            self._sstream_n = N
+        p_s, p_e, p_m, p_rp, p_rf = (C.c_void_p() for _ in range(5))
+        ne, rs = C.c_int32(0), C.c_int32(0)
+        after = _lib.Pcg64State()
+        _lib.check(L.ml2048_sched_stream_next(self._sstream, C.byref(p_s), C.byref(p_e), C.byref(p_m), C.byref(ne),
+                                              C.byref(after), C.byref(rs), C.byref(p_rp), C.byref(p_rf)),
+                   "sched_stream_next")
+        E = int(ne.value)
+
+        def view(ptr, nbytes, dtype):
+            return np.frombuffer((C.c_uint8 * nbytes).from_address(ptr.value), dtype=dtype)
+
+        sched = view(p_s, N * 12, np.int32).reshape(N, 3)
+        epochs = view(p_e, E * RAND_SIZE * 16, np.uint8).reshape(E, RAND_SIZE, 16)
+        masks = view(p_m, E * 4, np.uint32)
+        self._sstream_after = (after, rs.value, view(p_rp, RAND_SIZE * 16, np.uint8).reshape(RAND_SIZE, 16).copy(),
+                               view(p_rf, RAND_SIZE * 4, np.float32).copy())
+        return sched, epochs, masks  # views into the slot: valid until _release_schedule_async()
+
     def _pull_rng(self) -> None:
         """Make the host generator current again (before any host-side draw or inspection)."""
+        self._close_sched_stream()
         if not self._rng_on_device:
             return
         words = self._devrng.cpu().numpy().view(np.uint64)
@@ -372,6 +442,9 @@ class VecGame:
     def reset(self, seed: Optional[int] = None) -> None:
         """game_numba.py:606-617.  `_game_count` is NOT reset (only the constructor sets it)."""
         self._drop_prefetch()
+        if getattr(self, "_sstream", None) is not None:
+            self._sstream_after = None  # a reset discards whatever was drawn ahead
+            self._close_sched_stream()
         self._rng_on_device = False
         self._rng = HostRng(seed)
         self._fast_counter = 0
@@ -577,7 +650,10 @@ class VecGame:
             perm_dev, sched_dev, mask_dev, E = self._device_schedule(N)
         elif not fast:
             # the host schedule (independent of game state): one native call, or already drawn ahead
-            sched, epochs, masks = self._next_schedule(N)
+            if self._schedule_mode == "host-async":
+                sched, epochs, masks = self._next_schedule_async(N)
+            else:
+                sched, epochs, masks = self._next_schedule(N)
             if prefetch_next:
                 # start drawing the NEXT schedule right away: it then overlaps this call's packing,
                 # upload and launches as well as the GPU work
@@ -591,6 +667,8 @@ class VecGame:
             packed[o_sched:o_sched + N * 12] = sched.view(np.uint8).reshape(-1)
             packed[o_mask:] = masks.view(np.uint8)
             packed_dev = torch.from_numpy(packed).to(dev)
+            if self._schedule_mode == "host-async":
+                _lib.check(L.ml2048_sched_stream_release(self._sstream), "sched_stream_release")
             perm_dev = packed_dev[:o_sched]
             sched_dev = packed_dev[o_sched:o_sched + N * 12]
             mask_dev = packed_dev[o_mask:]

@@ -374,6 +374,35 @@ def test_device_schedule_rollouts_equal_host_schedule_rollouts(amd):
     assert a.digest() == b.digest()
 
 
+def test_async_host_schedule_equals_sync(amd):
+    """schedule='host-async' (native producer thread drawing ahead) == schedule='host', including
+    switching to the per-step API in between (the drawn-ahead schedules are then discarded)."""
+    M = 4096
+    a = amd.VecGame(M, "rank", schedule="host-async")
+    b = amd.VecGame(M, "rank", schedule="host")
+    a.reset(77)
+    b.reset(77)
+    act = np.random.default_rng(5).integers(0, 4, size=M)
+    for rnd in range(3):
+        for k in range(4):
+            a.rollout(96, masked=False, act_seed=1, act_counter=rnd * 1000 + k * 96)
+            b.rollout(96, masked=False, act_seed=1, act_counter=rnd * 1000 + k * 96)
+        assert a.digest() == b.digest()
+        assert a._rand_step == b._rand_step  # closes the stream, re-synchronises the host generator
+        for env in (a, b):
+            env.prepare()
+            env.step(act)
+        assert a._data.tobytes() == b._data.tobytes()
+        a.rollout(17)  # a different length re-opens the stream
+        b.rollout(17)
+    assert a._data.tobytes() == b._data.tobytes() and a._game_count == b._game_count
+    a.reset(3)
+    b.reset(3)
+    a.rollout(40)
+    b.rollout(40)
+    assert a.digest() == b.digest()
+
+
 def test_rollout_equals_stepwise_gpu(amd):
     """Same seeds -> the fused launch and N per-step launches leave identical device state."""
     M, N = 32768, 96
