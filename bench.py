@@ -147,6 +147,10 @@ def main():
     import torch
 
     import ml2048_amd as amd
+    from ml2048_amd import build as hip_build
+
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        hip_build.build()  # no-op when the in-tree library is up to date
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

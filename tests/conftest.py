@@ -25,3 +25,12 @@ def oracle():
 
     orc.build()
     return orc
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_libraries_built():
+    """Build (only if missing or stale) the in-tree HIP library before any test runs; hipcc
+    cross-compiles gfx950 without a GPU, so this works in the CPU container and on the GPU box."""
+    from ml2048_amd import build
+
+    build.build()
