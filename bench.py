@@ -151,6 +151,10 @@ def main():
 
     if int(os.environ.get("LOCAL_RANK", "0")) == 0:
         hip_build.build()  # no-op when the in-tree library is up to date
+    else:  # other ranks never build; they wait for rank 0 if it had to
+        t_wait = time.time()
+        while hip_build.is_stale() and time.time() - t_wait < 300:
+            time.sleep(0.5)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
