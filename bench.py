@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--boards", type=int, default=65536, help="M per GPU (C2: 65536)")
     ap.add_argument("--env-steps", type=int, default=128, help="N env steps per bench step (C2: 128)")
-    ap.add_argument("--mode", choices=["fused", "stepwise", "obs"], default="fused",
+    ap.add_argument("--mode", choices=["fused", "fused-traj", "stepwise", "obs"], default="fused",
                     help="fused: one rollout launch per bench step (default); stepwise: per-step API; "
                          "obs: per-step API + masked sampling + one-hot (C3 pipeline)")
     ap.add_argument("--masked", type=int, default=0, help="masked-uniform actions (default: unmasked, C2)")
@@ -190,11 +190,17 @@ def main():
     counter = [0]
     kern_ms = []
 
+    traj = None
+    if args.mode == "fused-traj":  # every step's transition materialised: 54 B written per board-step
+        from ml2048_amd import train_ops
+
+        traj = train_ops.new_buffers((N, M), dev, spec=train_ops.REPLAY_SPEC)
+
     def bench_step(timed: bool):
-        if args.mode == "fused":
+        if args.mode in ("fused", "fused-traj"):
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if timed else None
             env.rollout(N, masked=bool(args.masked), act_seed=7 + rank, act_counter=counter[0], kernel_events=ev,
-                        prefetch_next=bool(args.prefetch))
+                        prefetch_next=bool(args.prefetch), trajectory=traj)
             counter[0] += N
             if ev:
                 kern_ms.append(ev)
@@ -229,15 +235,18 @@ def main():
 
     # dominant kernel duration, HIP events on the launch stream
     roofline = None
-    if args.mode == "fused" and kern_ms:
+    if args.mode in ("fused", "fused-traj") and kern_ms:
         avg_ms = sum(a.elapsed_time(b) for a, b in kern_ms) / len(kern_ms)
-        alg_bytes = BYTES_PER_BOARD_STEP * M * N
+        # fused-traj: the 54 B/board-step of REPLAY_SPEC transitions are really written
+        alg_bytes = (54 if args.mode == "fused-traj" else BYTES_PER_BOARD_STEP) * M * N
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "k_rollout", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_launch": alg_bytes,
-                    "note": "algorithmic = 99 B/board-step x M x N per launch (what N per-step launches must move); "
-                            "the fused kernel keeps boards in registers, so measured HBM traffic is far below it"}
+                    "note": ("algorithmic = 99 B/board-step x M x N per launch (what N per-step launches must move); "
+                             "the fused kernel keeps boards in registers, so measured HBM traffic is far below it")
+                    if args.mode == "fused" else
+                    "algorithmic = the 54 B/board-step of REPLAY_SPEC transitions this launch really writes"}
     else:
         # per-step API: time the step kernel alone over a few launches
         evs = []
@@ -260,7 +269,7 @@ def main():
     if roofline and os.path.exists(traffic_file):
         try:
             tj = json.load(open(traffic_file))
-            key = f"{roofline['kernel']}:M={M}:N={N if args.mode == 'fused' else 1}"
+            key = f"{roofline['kernel']}:M={M}:N={N if args.mode == 'fused' else 1}" + (":traj" if args.mode == "fused-traj" else "")
             if key in tj:
                 roofline["traffic"] = tj[key]["bytes_per_launch"]
                 roofline["traffic_source"] = tj[key].get("source")

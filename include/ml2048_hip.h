@@ -260,6 +260,30 @@ int ml2048_rollout(void *stream, int64_t M, int64_t idx_base, const ml2048_state
                    const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed,
                    uint64_t act_counter0, uint8_t *actions_out, uint64_t *digests_out,
                    uint64_t *reset_flags, int32_t *last_reset);
+/*
+ * ml2048_rollout that also materialises every step's transition - the fused form of N x
+ * ml2048_record_transition (Trainer.on_stepped, run_train3.py:125-155): each non-NULL pointer is a
+ * [N][M] buffer (contiguous in the game dimension) with the REPLAY_SPEC dtypes
+ * (src/ml2048/replay.py:10-20).  54 bytes are written per board-step when all nine are given, which
+ * makes this variant HBM-write-bound rather than VALU-bound.
+ */
+typedef struct ml2048_traj {
+    int8_t *state;               /* [N][M][16] board before the move (after the deal)  */
+    uint8_t *valid_actions;      /* [N][M][4]  its mask                                */
+    int8_t *action;              /* [N][M]     sampled action                          */
+    float *action_log_prob;      /* [N][M]     -log(#valid) (or -log 4 unmasked)       */
+    float *reward;               /* [N][M]     record field after the step             */
+    int8_t *next_state;          /* [N][M][16]                                         */
+    uint8_t *next_valid_actions; /* [N][M][4]                                          */
+    int32_t *step;               /* [N][M]                                             */
+    uint8_t *terminated;         /* [N][M]     bool                                    */
+} ml2048_traj;
+int ml2048_rollout_traj(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
+                        const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,
+                        const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed,
+                        uint64_t act_counter0, uint64_t *reset_flags, int32_t *last_reset,
+                        const ml2048_traj *traj);
+
 /* The same fused rollout in fast (rocRAND) spawn mode: no host schedule at all.  Equals N calls of
  * ml2048_prepare_fast(counter = 2*(spawn_counter0+t)) / ml2048_sample_actions / ml2048_step_fast(
  * counter = 2*(spawn_counter0+t)+1); bit-exact against the oracle's orc_*_fast, not against numba. */

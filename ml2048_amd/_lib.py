@@ -25,6 +25,13 @@ class Ml2048Error(RuntimeError):
     pass
 
 
+class Traj(C.Structure):
+    """struct ml2048_traj (include/ml2048_hip.h)."""
+
+    _fields_ = [(n, C.c_void_p) for n in ("state", "valid_actions", "action", "action_log_prob", "reward",
+                                           "next_state", "next_valid_actions", "step", "terminated")]
+
+
 class Pcg64State(C.Structure):
     """struct ml2048_pcg64 (include/ml2048_hip.h)."""
 
@@ -81,6 +88,9 @@ _SIGNATURES = {
     "ml2048_rollout": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_int32, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ml2048_rollout_traj": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_int32, C.c_void_p,
+                                      C.c_void_p, C.c_int32, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
+                                      C.c_void_p, C.c_void_p, C.POINTER(Traj)]),
     "ml2048_rollout_fast": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_int32, C.c_double,
                                       C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

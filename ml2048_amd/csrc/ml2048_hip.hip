@@ -675,7 +675,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                                                     uint64_t *__restrict__ digests_out,
                                                     uint64_t *__restrict__ reset_flags, int64_t flag_words,
                                                     int32_t *__restrict__ last_reset, uint64_t spawn_seed,
-                                                    uint64_t spawn_counter0, uint64_t thr) {
+                                                    uint64_t spawn_counter0, uint64_t thr, ml2048_traj traj) {
     // The schedule kernel of the NEXT rollout (csrc/devrng.hip) may share a CU with one of these
     // workgroups; the rollout is the critical path, so its waves win the issue arbitration.
     __builtin_amdgcn_s_setprio(1);
@@ -774,6 +774,20 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
             invalid = 0;
         } else {
             invalid = 1;
+        }
+        // ---- optional trajectory: this step's transition into [N][M] buffers with the REPLAY_SPEC
+        //      dtypes (replay.py:10-20), i.e. what N x ml2048_record_transition would write
+        if (live) {
+            const int64_t o = (int64_t)t * M + i;
+            if (traj.state) reinterpret_cast<uint4 *>(traj.state)[o] = make_uint4(prev_board.r[0], prev_board.r[1], prev_board.r[2], prev_board.r[3]);
+            if (traj.next_state) reinterpret_cast<uint4 *>(traj.next_state)[o] = make_uint4(s.board.r[0], s.board.r[1], s.board.r[2], s.board.r[3]);
+            if (traj.valid_actions) reinterpret_cast<uint32_t *>(traj.valid_actions)[o] = prev_valid;
+            if (traj.next_valid_actions) reinterpret_cast<uint32_t *>(traj.next_valid_actions)[o] = s.valid;
+            if (traj.action) traj.action[o] = (int8_t)action;
+            if (traj.action_log_prob) traj.action_log_prob[o] = neg_log_count(cnt);
+            if (traj.reward) traj.reward[o] = s.reward;
+            if (traj.step) traj.step[o] = s.step;
+            if (traj.terminated) traj.terminated[o] = s.terminated != 0;
         }
         if (digests_out) {
             if (merged_stale) {
@@ -1118,14 +1132,23 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
                           const uint8_t *perm_epochs, const uint32_t *two_masks, const int32_t *schedule,
                           int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0, uint8_t *actions_out,
                           uint64_t *digests_out, uint64_t *reset_flags, int32_t *last_reset, uint64_t spawn_seed,
-                          uint64_t spawn_counter0, double two_prob) {
+                          uint64_t spawn_counter0, double two_prob, const ml2048_traj *traj_or_null) {
+    ml2048_traj traj = {};
+    if (traj_or_null) {
+        traj = *traj_or_null;
+        if (((uintptr_t)traj.state | (uintptr_t)traj.next_state) % 16)
+            return fail(ML2048_E_ALIGN, "traj.state/next_state must be 16-byte aligned");
+        if (((uintptr_t)traj.valid_actions | (uintptr_t)traj.next_valid_actions | (uintptr_t)traj.reward |
+             (uintptr_t)traj.step | (uintptr_t)traj.action_log_prob) % 4)
+            return fail(ML2048_E_ALIGN, "4-byte trajectory outputs must be 4-byte aligned");
+    }
     const dim3 grid((unsigned)cdiv(M, kBlock)), block(kBlock);
     const int64_t W = ml2048_rollout_flag_words(M);
     const uint64_t thr = two_threshold(two_prob);
 #define ML_LAUNCH(K, F)                                                                                      \
     hipLaunchKernelGGL((k_rollout<K, F>), grid, block, 0, s, *st, M, idx_base, N, perm_epochs, two_masks,   \
                        schedule, masked, act_seed, act_counter0, actions_out, digests_out, reset_flags, W,  \
-                       last_reset, spawn_seed, spawn_counter0, thr)
+                       last_reset, spawn_seed, spawn_counter0, thr, traj)
 #define ML_KIND(F)                                                                   \
     switch (reward_kind) {                                                           \
     case ML2048_REWARD_NORMAL: ML_LAUNCH(REWARD_NORMAL, F); break;                   \
@@ -1155,7 +1178,22 @@ int ml2048_rollout(void *stream, int64_t M, int64_t idx_base, const ml2048_state
     if ((uintptr_t)perm_epochs % 16) return fail(ML2048_E_ALIGN, "perm_epochs must be 16-byte aligned");
     if (idx_base < 0) return fail(ML2048_E_INVALID, "idx_base must be >= 0");
     return launch_rollout((hipStream_t)stream, false, M, idx_base, st, N, perm_epochs, two_masks, schedule, reward_kind,
-                          masked, act_seed, act_counter0, actions_out, digests_out, reset_flags, last_reset, 0, 0, 0.0);
+                          masked, act_seed, act_counter0, actions_out, digests_out, reset_flags, last_reset, 0, 0, 0.0,
+                          nullptr);
+}
+
+int ml2048_rollout_traj(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
+                        const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,
+                        const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0,
+                        uint64_t *reset_flags, int32_t *last_reset, const ml2048_traj *traj) {
+    if (int rc = check_state(M, st)) return rc;
+    if (N <= 0 || n_epochs <= 0) return fail(ML2048_E_INVALID, "N=%d n_epochs=%d must be positive", N, n_epochs);
+    if (!perm_epochs || !two_masks || !schedule || !reset_flags || !last_reset || !traj)
+        return fail(ML2048_E_INVALID, "perm_epochs/two_masks/schedule/reset_flags/last_reset/traj is NULL");
+    if ((uintptr_t)perm_epochs % 16) return fail(ML2048_E_ALIGN, "perm_epochs must be 16-byte aligned");
+    if (idx_base < 0) return fail(ML2048_E_INVALID, "idx_base must be >= 0");
+    return launch_rollout((hipStream_t)stream, false, M, idx_base, st, N, perm_epochs, two_masks, schedule, reward_kind,
+                          masked, act_seed, act_counter0, nullptr, nullptr, reset_flags, last_reset, 0, 0, 0.0, traj);
 }
 
 int ml2048_rollout_fast(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
@@ -1168,7 +1206,7 @@ int ml2048_rollout_fast(void *stream, int64_t M, int64_t idx_base, const ml2048_
     if (idx_base < 0) return fail(ML2048_E_INVALID, "idx_base must be >= 0");
     return launch_rollout((hipStream_t)stream, true, M, idx_base, st, N, nullptr, nullptr, nullptr, reward_kind, masked,
                           act_seed, act_counter0, actions_out, digests_out, reset_flags, last_reset, spawn_seed,
-                          spawn_counter0, two_prob);
+                          spawn_counter0, two_prob, nullptr);
 }
 
 int ml2048_rollout_finish_ids(void *stream, int64_t M, const ml2048_state *st, int32_t N,

@@ -628,7 +628,8 @@ class VecGame:
 
     def rollout(self, n_steps: int, *, masked: bool = True, act_seed: int = 0, act_counter: int = 0,
                 record_actions: bool = False, digests: bool = False, finish_ids: bool = True,
-                kernel_events: Optional[tuple] = None, prefetch_next: bool = False):
+                kernel_events: Optional[tuple] = None, prefetch_next: bool = False,
+                trajectory: Optional[dict] = None):
         """N x {prepare; uniform-random actions; step} fused into one kernel launch, bit-exact
         with the per-step API on the same seeds (both spawn modes; spawn="rocrand" needs no host
         schedule and is purely GPU-bound).
@@ -639,6 +640,8 @@ class VecGame:
         immediately around the rollout kernel (bench.py times the dominant kernel with it).
         prefetch_next: draw the host schedule of the next rollout(n_steps) on a worker thread while
         this one runs on the GPU (results are identical either way).
+        trajectory: dict of [N, M, ...] device tensors keyed like REPLAY_SPEC (train_ops.new_buffers((N, M),
+        ...)); every step's transition is written into them by the same launch (table spawn mode).
         """
         N, M, dev = int(n_steps), self._size, self.device
         if N <= 0:
@@ -685,7 +688,25 @@ class VecGame:
         with self._dev_ctx():
             if kernel_events is not None:
                 kernel_events[0].record(torch.cuda.current_stream(dev))
-            if fast:  # rocRAND spawn: no host schedule at all
+            if trajectory is not None:
+                if fast or record_actions or digests:
+                    raise ValueError("trajectory= is for table spawn mode, without record_actions/digests")
+                tr = _lib.Traj()
+                for name, dt in (("state", torch.int8), ("valid_actions", torch.bool), ("action", torch.int8),
+                                 ("action_log_prob", torch.float32), ("reward", torch.float32),
+                                 ("next_state", torch.int8), ("next_valid_actions", torch.bool),
+                                 ("step", torch.int32), ("terminated", torch.bool)):
+                    buf = trajectory.get(name)
+                    if buf is None:
+                        continue
+                    assert buf.is_contiguous() and buf.dtype == dt and buf.device == dev and \
+                        tuple(buf.shape[:2]) == (N, M), (name, buf.dtype, tuple(buf.shape))
+                    setattr(tr, name, buf.data_ptr())
+                _lib.check(L.ml2048_rollout_traj(
+                    self._stream(), M, self._idx_base, self._st(), N, perm_dev.data_ptr(), mask_dev.data_ptr(),
+                    E, sched_dev.data_ptr(), self._reward_kind, int(masked), int(act_seed), int(act_counter),
+                    flags.data_ptr(), last.data_ptr(), C.byref(tr)), "rollout_traj")
+            elif fast:  # rocRAND spawn: no host schedule at all
                 _lib.check(L.ml2048_rollout_fast(
                     self._stream(), M, self._idx_base, self._st(), N, self._two_prob, self._spawn_seed,
                     self._fast_counter, self._reward_kind, int(masked), int(act_seed), int(act_counter),

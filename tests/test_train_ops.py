@@ -90,3 +90,31 @@ def test_record_transition_equals_on_stepped_copies():
         assert torch.equal(buf[k], ref[k]), k
     assert bool(buf["terminated"].any()) or True
     assert int(buf["reward"].abs().sum().item()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("masked", [True, False])
+def test_fused_trajectory_equals_stepwise_recording(masked):
+    """rollout(trajectory=...) writes, in one launch, what N x {prepare; sample; step;
+    record_transition} write."""
+    import ml2048_amd as amd
+    from ml2048_amd import train_ops
+
+    M, N = 5000, 70
+    a = amd.VecGame(M, amd.reward_fn_improved)
+    b = amd.VecGame(M, amd.reward_fn_improved)
+    a.reset(21)
+    b.reset(21)
+    traj = train_ops.new_buffers((N, M), a.device, spec=train_ops.REPLAY_SPEC)
+    a.rollout(N, masked=masked, act_seed=6, act_counter=50, trajectory=traj)
+    ref = train_ops.new_buffers((1, N, M), b.device, spec=train_ops.REPLAY_SPEC)
+    pol = amd.RandomPolicy(seed=6, masked=masked)
+    pol.counter = 50
+    for t in range(N):
+        b.prepare_torch()
+        act, lp = pol.sample_actions_u8(b.valid_actions)
+        b.step_torch(act)
+        train_ops.record_transition(b, act, lp, ref, 0, t)
+    for k in train_ops.REPLAY_SPEC:
+        assert torch.equal(traj[k], ref[k][0]), k
+    assert a._data.tobytes() == b._data.tobytes()
