@@ -81,8 +81,6 @@ def host_cpu_share() -> int:
 def cpu_baseline(M: int, N: int, seed: int, seconds: float):
     """Time the CPU oracle on the host cores: repeated N-step rollouts of M boards (same seeds,
     same action stream definition) until ~`seconds` have elapsed."""
-    import numpy as np  # noqa: F401
-
     from oracle import oracle as orc
 
     lib_path = None

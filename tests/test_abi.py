@@ -106,8 +106,6 @@ def test_reward_sentinels_match_known_answer(golden_dir):
 
 def test_host_rng_matches_golden(golden_dir):
     """The product's host RNG schedule (not the oracle's copy) against the reference fixtures."""
-    import hashlib
-
     import numpy as np
 
     from ml2048_amd.hostrng import HostRng

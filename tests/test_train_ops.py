@@ -1,7 +1,6 @@
 """Rollout consumers: GAE scan and transition recording.
 CPU part: the oracle against the reference's own torch expression (src/ml2048/gae.py:50, :58-68).
 GPU part (-m gpu): the HIP kernels against both."""
-import numpy as np
 import pytest
 import torch
 
