@@ -14,22 +14,23 @@ from .game import VecGame, VecStepResult
 from .policy import Policy, RandomPolicy
 
 
-class EventEmitter:  # src/ml2048/event.py:7-38
+class EventEmitter:
+    """Named callback lists (the contract of src/ml2048/event.py:7-38: add_listener / emit)."""
+
     def __init__(self):
-        self.listeners: dict[str, list[Callable[..., Any]]] = collections.defaultdict(list)
+        self._hooks: dict[str, list[Callable[..., Any]]] = collections.defaultdict(list)
 
     def add_listener(self, name: str, fn: Callable[..., Any], prepend: bool = False) -> None:
-        if prepend:
-            self.listeners[name].insert(0, fn)
-        else:
-            self.listeners[name].append(fn)
+        hooks = self._hooks[name]
+        hooks.insert(0 if prepend else len(hooks), fn)
 
     def has_listeners(self, name: str) -> bool:
-        return bool(self.listeners.get(name))
+        return len(self._hooks.get(name, ())) > 0
 
     def emit(self, name: str, args: tuple[Any, ...], kwargs: dict[str, Any] | None = None) -> None:
-        for fn in self.listeners.get(name, ()):  # noqa: B007
-            fn(*args, **(kwargs or {}))
+        extra = kwargs or {}
+        for hook in tuple(self._hooks.get(name, ())):
+            hook(*args, **extra)
 
 
 class VecRunner:
@@ -111,22 +112,19 @@ class RunnerStats:
             self._term.zero_()
 
     def summary(self) -> list[tuple]:
+        """[(tile value, games, share)] from the largest tile down, skipping empty bins
+        (same rows as the reference's RunnerStats.summary, runner.py:168-179)."""
         self.sync()
-        total = self.counts.sum()
-        entries = []
-        for power in range(16, 0, -1):
-            count = self.counts[power].item()
-            if count == 0:
-                continue
-            entries.append((2**power, count, count / total))
-        return entries
+        total = int(self.counts.sum())
+        rows = [(1 << e, int(self.counts[e])) for e in range(16, 0, -1) if self.counts[e]]
+        return [(tile, n, n / total) for tile, n in rows]
 
     @classmethod
     def combine(cls, seq: Sequence["RunnerStats"]) -> "RunnerStats":
         """Host-side gather over shards / GPUs (no collective needed: 20 ints per shard)."""
-        for s in seq:
-            s.sync()
-        result = cls()
-        result.counts = np.sum([s.counts for s in seq], axis=0)
-        result.terminated_count = sum(s.terminated_count for s in seq)
-        return result
+        merged = cls()
+        for part in seq:
+            part.sync()
+            merged.counts += part.counts
+            merged.terminated_count += part.terminated_count
+        return merged
