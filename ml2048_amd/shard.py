@@ -51,3 +51,67 @@ def max_over_ranks(seconds: float, dist=None) -> float:
             t = t.cuda()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+class GlobalVecGame:
+    """SURVEY 8e "global mode": K shards (one per device, or several on one device) that together are
+    bit-exact with ONE reference `VecGame(total)` - same table rows (idx_base), same host draw per
+    call, and the reference's ascending game ids across shard boundaries.
+
+    The ids are the only cross-shard dependency: shard k's new games are numbered after those of
+    shards 0..k-1, so `prepare()` first reads the K terminated counts (K small D2H reads), then
+    gives every shard its id base and lets it deal.  Throughput runs should use independent replicas
+    (`ShardPlan`); this class exists for exact reproduction of a single big game on several GPUs.
+    """
+
+    def __init__(self, total: int, reward_fn=None, *, devices, two_prob: float = 0.8):
+        from .game import VecGame
+
+        devices = list(devices)
+        if total <= 0 or not devices:
+            raise ValueError(f"total={total} devices={devices}")
+        self._size = int(total)
+        self.plans = [ShardPlan.make(total, k, len(devices)) for k in range(len(devices))]
+        self.shards = [VecGame(p.boards, reward_fn, two_prob=two_prob, device=d, idx_base=p.idx_base)
+                       for p, d in zip(self.plans, devices)]
+        self._game_count = 0
+        self.reset()
+
+    def reset(self, seed=None) -> None:
+        from .hostrng import HostRng
+
+        master = HostRng(seed)
+        for sh in self.shards:  # every shard replays the same host stream (the draws do not depend on game state)
+            sh.reset(0)
+            sh._rng = master.clone()
+            sh._upload_tables()
+
+    def prepare(self):
+        counts = [int((sh.terminated != 0).sum().item()) for sh in self.shards]
+        base = self._game_count
+        out = []
+        for sh, p, n in zip(self.shards, self.plans, counts):
+            sh._game_count_dev.fill_(base)
+            (idx,) = sh.prepare()
+            assert idx.size == n
+            out.append(idx + p.idx_base)
+            base += n
+        self._game_count = base
+        return (np.concatenate(out),)
+
+    def step(self, actions):
+        actions = np.ascontiguousarray(actions)
+        assert actions.shape == (self._size,), actions.shape
+        res = [sh.step(actions[p.idx_base:p.idx_base + p.boards]) for sh, p in zip(self.shards, self.plans)]
+        return {k: np.concatenate([r[k] for r in res]) for k in res[0]}
+
+    @property
+    def _data(self):
+        return np.concatenate([sh._data for sh in self.shards])
+
+    def summary(self):
+        counts = sum(sh.histogram().cpu().numpy().astype(np.int64) for sh in self.shards)
+        total = int(counts.sum())
+        rows = [(2 ** k, int(c), int(c) / total) for k, c in enumerate(counts) if c]
+        rows.sort(key=lambda r: r[0], reverse=True)
+        return rows

@@ -203,6 +203,31 @@ def test_idx_base_shards_equal_one_global_game(amd, oracle):
         assert np.array_equal(got[f], whole._data[f]), f
 
 
+def test_global_mode_shards_equal_one_reference_game_including_ids(amd, oracle):
+    """SURVEY 8e global mode: three shards (here on one GPU) == one game of the total size, ids and
+    the returned reset indices included."""
+    from ml2048_amd.shard import GlobalVecGame
+
+    M, N, seed = 3001, 400, 12
+    g = GlobalVecGame(M, "improved", devices=["cuda:0"] * 3)
+    ref = oracle.OracleVecGame(M, "improved")
+    g.reset(seed)
+    ref.reset(seed)
+    arng = np.random.default_rng(2)
+    for s in range(N):
+        (i1,) = g.prepare()
+        (i2,) = ref.prepare()
+        assert np.array_equal(i1, i2), s
+        a = arng.integers(0, 4, size=M)
+        r1 = g.step(a)
+        r2 = ref.step(a)
+        if s % 50 == 0 or s == N - 1:
+            assert g._data.tobytes() == ref._data.tobytes(), s
+            assert np.array_equal(r1["prev_state"], r2["prev_state"])
+    assert g._game_count == ref._game_count > M
+    assert g.summary() == ref.summary()
+
+
 def test_high_exponent_boards_h9_h10(amd, oracle, torch_cuda):
     """Tiles 2^14..2^17: merges whose bucket index is 16/17 (H9) and un-encodable one-hots (H10)."""
     M = 512
