@@ -317,6 +317,29 @@ def test_rollout_c2_fused_vs_oracle(amd, oracle):
     _check_rollout(amd, oracle, 65536, 128, 20241008, "normal", masked=False)
 
 
+def test_rollout_c4_total_size_on_one_gpu_vs_oracle(amd, oracle):
+    """BASELINE config 4's TOTAL size (M = 2 097 152 boards = 8 x 262 144) as one fused rollout on one
+    GPU, against the oracle: per-step digests of every board, re-deal counts, final records and ids.
+    (The 8-GPU run shards this into 8 independent replicas; this is the largest single-shard case.)"""
+    M, N = 2097152, 48
+    env = amd.VecGame(M, "normal")
+    env.reset(20241008)
+    out = env.rollout(N, masked=False, act_seed=7, act_counter=0, record_actions=True, digests=True)
+    actions = out["actions"].cpu().numpy()
+    dig = out["digests"].cpu().numpy().view(np.uint64)
+    resets = out["step_resets"].cpu().numpy()
+    ref = oracle.OracleVecGame(M, "normal")
+    ref.reset(20241008)
+    for s in range(N):
+        (ridx,) = ref.prepare()
+        assert resets[s] == ridx.size, s
+        ref.step(actions[s])
+        assert int(dig[s]) == ref.digest(with_id=False), f"digest differs at step {s}"
+    assert env.digest() == ref.digest()          # includes the ids assigned after the fact
+    assert env._game_count == ref._game_count >= M
+    assert env._data.tobytes() == ref._data.tobytes()
+
+
 @pytest.mark.parametrize("M,N,masked,reward", [(1000, 300, True, "improved"), (65, 64, False, "rank"),
                                                (4096, 256, True, "maxcell")])
 def test_rollout_small_cases(amd, oracle, M, N, masked, reward):
