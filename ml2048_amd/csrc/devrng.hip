@@ -44,7 +44,9 @@ __device__ __forceinline__ uint64_t xsl_rr(u128 st) {
 constexpr int kThreads = 1024;
 constexpr int kStepsPerThread = 12;                       // LCG steps generated per thread
 constexpr int kWords = kThreads * kStepsPerThread * 2;    // 24576 words per regeneration window
-constexpr int kSeg = kWords / kThreads;                   // 24 words per thread segment
+constexpr int kRelax = 512;                               // threads that walk the automaton (one wave per SIMD:
+                                                          // the walk is a dependent chain, more waves only slow it)
+constexpr int kSeg = kWords / kRelax;                     // 48 words per relaxation segment
 
 // workspace layout (u128 pairs {P, G}: state after k steps = P s + G c)
 //   [0, 1024)      k = 12 t       (per-thread jump)
@@ -95,16 +97,22 @@ __device__ __forceinline__ uint32_t accept_bits(uint32_t low) {
     return m;
 }
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would
+// wait for the epoch-table and float-table global stores issued just before it (several us each)
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xC07F); // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+}
+
 __global__ __launch_bounds__(kThreads) void k_devrng_schedule(const Jump *__restrict__ ws, ml2048_devrng *rng,
                                                               uint8_t *randperm, float *randfloat, int N,
                                                               double two_prob, int32_t *__restrict__ schedule,
                                                               uint8_t *__restrict__ perm_epochs,
                                                               uint32_t *__restrict__ two_masks, int max_epochs,
                                                               int32_t *__restrict__ n_epochs) {
-    __shared__ uint8_t nib[kWords + 8];          // low nibble of every word of the current window
-    __shared__ uint8_t rows[16][kThreads];       // the permutation table, rows[i][r] = table[r][i]
+    __shared__ uint32_t words[kWords + 8];       // the 32-bit words of the current window (96 KiB)
     __shared__ uint16_t acc_tab[16];
-    __shared__ uint8_t seg_state[kThreads + 1];  // automaton state at each segment start
+    __shared__ uint8_t seg_state[2][kRelax + 1]; // automaton state (i-1) at each segment start, ping-pong
     __shared__ int scan_tmp[kThreads / 64];
     __shared__ uint32_t row_start[kThreads + 1];
     __shared__ uint32_t s_float_bits[16];
@@ -120,12 +128,13 @@ __global__ __launch_bounds__(kThreads) void k_devrng_schedule(const Jump *__rest
     int err = 0;
 
     if (t < 16) acc_tab[t] = (uint16_t)accept_bits((uint32_t)t);
-    {   // my row of the table -> LDS (column-major) and epoch 0 of the output
+    // my row of the table lives in two 64-bit registers for the whole kernel; epoch 0 of the output
+    uint64_t row_lo, row_hi;
+    {
         const uint4 v = reinterpret_cast<const uint4 *>(randperm)[t];
         reinterpret_cast<uint4 *>(perm_epochs)[t] = v;
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int i = 0; i < 16; ++i) rows[i][t] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+        row_lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
+        row_hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
     }
     if (wave == 0) {
         const float f = randfloat[lane & 15];
@@ -133,6 +142,7 @@ __global__ __launch_bounds__(kThreads) void k_devrng_schedule(const Jump *__rest
         if (lane == 0) two_masks[0] = (uint32_t)(m & 0xFFFFull);
     }
     int E = 1;
+    const u128 myP = ws[t].P, myG = ws[t].G; // my jump to LCG step 12 t (loaded once)
     __syncthreads();
 #ifdef ML2048_DEVRNG_STATS
     long long t_gen = 0, t_relax = 0, t_rows = 0, t_replay = 0, t_float = 0, sweeps = 0, t_all = clock64();
@@ -159,59 +169,71 @@ __global__ __launch_bounds__(kThreads) void k_devrng_schedule(const Jump *__rest
             ML_T0
             // (1) the word window: [pending half] + halves of the next kThreads*12 outputs
             const int p0 = has32 ? 1 : 0;
-            if (p0 && t == 0) nib[0] = (uint8_t)(buf32 & 15u);
+            if (p0 && t == 0) words[0] = buf32;
             {
-                u128 st = ws[t].P * cur + ws[t].G * inc;
-                uint8_t *dst = nib + p0 + 2 * kStepsPerThread * t;
+                u128 st = myP * cur + myG * inc;
+                uint32_t *dst = words + p0 + 2 * kStepsPerThread * t;
 #pragma unroll 4
                 for (int k = 0; k < kStepsPerThread; ++k) {
                     st = st * A + inc;
                     const uint64_t out = xsl_rr(st);
-                    dst[2 * k] = (uint8_t)(out & 15u);
-                    dst[2 * k + 1] = (uint8_t)((out >> 32) & 15u);
+                    dst[2 * k] = (uint32_t)out;
+                    dst[2 * k + 1] = (uint32_t)(out >> 32);
                 }
             }
-            seg_state[t] = 15;
+            if (t < kRelax) seg_state[0][t] = seg_state[1][t] = 14; // i = 15
             __syncthreads();
             ML_T(t_gen)
-            // (2) relaxation: state at the start of my segment.  The acceptance bitmaps of my 24
-            //     words are loaded once (they do not depend on the state), so a sweep is a pure ALU
-            //     chain: i -= (bits_k >> i) & 1 - no LDS latency inside it.
-            uint32_t accw[kSeg / 2]; // two 16-bit bitmaps per register
-            {
-                const uint8_t *seg = nib + kSeg * t;
+            // (2) relaxation over kRelax segments of kSeg words (threads 0..kRelax-1, one wave per
+            //     SIMD).  The acceptance bitmaps of my words are loaded once (they do not depend on the
+            //     state), so a sweep is a pure ALU chain: i -= (bits_k >> i) & 1.
+            //     State is kept as s = i-1 (0..14) and the bitmaps pre-shifted, so one word is
+            //     lshr/and/sub/min: s' = min_u32(s - accepted, 14) (0 - 1 wraps to 0xFFFFFFFF -> 14 = next row).
+            //     Sweeps ping-pong between two state arrays (one barrier each); convergence is only
+            //     tested every 4th sweep.
+            uint32_t accw[kSeg / 2]; // two 15-bit bitmaps per register (bit s <=> accepted in state s+1)
+            const bool walker = t < kRelax;
+            if (walker) {
+                const uint32_t *seg = words + kSeg * t;
 #pragma unroll
                 for (int k = 0; k < kSeg; k += 2)
-                    accw[k / 2] = (uint32_t)acc_tab[seg[k]] | ((uint32_t)acc_tab[seg[k + 1]] << 16);
+                    accw[k / 2] = ((uint32_t)acc_tab[seg[k] & 15u] >> 1) | (((uint32_t)acc_tab[seg[k + 1] & 15u] >> 1) << 16);
             }
-            for (;;) {
-                int i = seg_state[t];
+            int buf = 0;
+            for (int sweep = 1;; ++sweep) {
+                int changed = 0;
+                if (walker) {
+                    uint32_t sst = seg_state[buf][t];
 #pragma unroll
-                for (int k = 0; k < kSeg; ++k) {
-                    i -= (accw[k / 2] >> (16 * (k & 1) + i)) & 1;
-                    i = i == 0 ? 15 : i;
+                    for (int k = 0; k < kSeg; ++k) {
+                        const uint32_t acc = (accw[k / 2] >> (16 * (k & 1) + sst)) & 1u;
+                        sst = min(sst - acc, 14u);
+                    }
+                    if (t + 1 < kRelax) {
+                        changed = seg_state[buf][t + 1] != (uint8_t)sst;
+                        seg_state[buf ^ 1][t + 1] = (uint8_t)sst;
+                    }
                 }
-                const int nxt = t + 1 < kThreads ? seg_state[t + 1] : i;
-                const int changed = (t + 1 < kThreads) && nxt != i;
-                __syncthreads();
-                if (changed) seg_state[t + 1] = (uint8_t)i;
+                buf ^= 1;
 #ifdef ML2048_DEVRNG_STATS
                 ++sweeps;
 #endif
-                if (!__syncthreads_or(changed)) break;
+                if ((sweep & 3) == 0) {
+                    if (!__syncthreads_or(changed)) break; // nobody changed in THIS sweep: fixed point
+                } else {
+                    __syncthreads();
+                }
             }
             ML_T(t_relax)
             // (3) number the rows: completions per segment -> exclusive scan -> row starts
             int cnt = 0;
-            {
-                int i = seg_state[t];
+            if (walker) {
+                uint32_t sst = seg_state[buf][t];
 #pragma unroll
                 for (int k = 0; k < kSeg; ++k) {
-                    i -= (accw[k / 2] >> (16 * (k & 1) + i)) & 1;
-                    if (i == 0) {
-                        i = 15;
-                        ++cnt;
-                    }
+                    const uint32_t acc = (accw[k / 2] >> (16 * (k & 1) + sst)) & 1u;
+                    cnt += (sst == 0u) & acc; // accepted in state i = 1: the row is complete
+                    sst = min(sst - acc, 14u);
                 }
             }
             int incl = cnt;
@@ -225,16 +247,17 @@ __global__ __launch_bounds__(kThreads) void k_devrng_schedule(const Jump *__rest
             int before = incl - cnt;
             for (int w = 0; w < wave; ++w) before += scan_tmp[w];
             if (t == 0) row_start[0] = 0;
-            {
-                int i = seg_state[t], done = before;
+            if (walker) {
+                uint32_t sst = seg_state[buf][t];
+                int done = before;
 #pragma unroll
                 for (int k = 0; k < kSeg; ++k) {
-                    i -= (accw[k / 2] >> (16 * (k & 1) + i)) & 1;
-                    if (i == 0) {
-                        i = 15;
+                    const uint32_t acc = (accw[k / 2] >> (16 * (k & 1) + sst)) & 1u;
+                    if ((sst == 0u) & acc) {
                         ++done; // row (done-1) just completed; row `done` starts at the next word
                         if (done <= kThreads) row_start[done] = (uint32_t)(kSeg * t + k + 1);
                     }
+                    sst = min(sst - acc, 14u);
                 }
             }
             __syncthreads();
@@ -253,64 +276,55 @@ __global__ __launch_bounds__(kThreads) void k_devrng_schedule(const Jump *__rest
                 break;
             }
             ML_T(t_rows)
-            // (4) replay my row and apply its swaps (Generator.permuted, i = 15..1)
+            // (4) replay my row and apply its swaps (Generator.permuted, i = 15..1) to the row held
+            //     in two 64-bit registers: swapping bytes i and j = xor both with (a ^ b)
             {
                 uint32_t pos = row_start[t];
                 int i = 15;
+                uint32_t nextw = words[pos];
                 while (i >= 1) {
-                    const uint32_t low = nib[pos++];
-                    if ((acc_tab[low] >> i) & 1) {
-                        const uint32_t mask = i >= 8 ? 15u : i >= 4 ? 7u : i >= 2 ? 3u : 1u;
-                        const uint32_t j = low & mask;
-                        const uint8_t a = rows[i][t], b = rows[j][t];
-                        rows[j][t] = a;
-                        rows[i][t] = b;
+                    const uint32_t low = nextw & 15u;
+                    nextw = words[++pos]; // one word ahead: hides the LDS latency behind the swap
+                    const uint32_t mask = i >= 8 ? 15u : i >= 4 ? 7u : i >= 2 ? 3u : 1u;
+                    const uint32_t j = low & mask;
+                    if (j <= (uint32_t)i) {
+                        const uint64_t hi_i = (uint32_t)i >= 8u ? row_hi : row_lo, hi_j = j >= 8u ? row_hi : row_lo;
+                        const uint32_t si = 8u * ((uint32_t)i & 7u), sj = 8u * (j & 7u);
+                        const uint64_t x = ((hi_i >> si) ^ (hi_j >> sj)) & 0xFFull;
+                        const uint64_t xi = x << si, xj = x << sj;
+                        row_lo ^= ((uint32_t)i < 8u ? xi : 0ull) ^ (j < 8u ? xj : 0ull);
+                        row_hi ^= ((uint32_t)i >= 8u ? xi : 0ull) ^ (j >= 8u ? xj : 0ull);
                         --i;
                     }
                 }
-                uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll
-                for (int q = 0; q < 16; ++q) w[q >> 2] |= (uint32_t)rows[q][t] << (8 * (q & 3));
-                reinterpret_cast<uint4 *>(perm_epochs)[(size_t)E * kThreads + t] = make_uint4(w[0], w[1], w[2], w[3]);
+                reinterpret_cast<uint4 *>(perm_epochs)[(size_t)E * kThreads + t] =
+                    make_uint4((uint32_t)row_lo, (uint32_t)(row_lo >> 32), (uint32_t)row_hi, (uint32_t)(row_hi >> 32));
             }
-            __syncthreads();
             ML_T(t_replay)
-            // (5) Generator.random(float32): word used+t of the window; needs the full 32 bits, so
-            //     the output is recomputed: W[k] (k >= p0) = half (k-p0)&1 of LCG step (k-p0)/2 + 1
+            // (5) Generator.random(float32): word used+t of the window
             {
-                const uint32_t k = used + (uint32_t)t;
-                uint32_t word;
-                if (k < (uint32_t)p0) {
-                    word = buf32;
-                } else {
-                    const uint32_t stp = (k - p0) / 2;           // 0-based step inside the window
-                    const uint32_t blk = stp / kStepsPerThread;  // table jump + a few single steps
-                    u128 st = ws[blk].P * cur + ws[blk].G * inc;
-                    for (uint32_t q = 0; q <= stp - blk * kStepsPerThread; ++q) st = st * A + inc;
-                    const uint64_t out = xsl_rr(st);
-                    word = ((k - p0) & 1u) ? (uint32_t)(out >> 32) : (uint32_t)out;
-                }
+                const uint32_t word = words[used + (uint32_t)t];
                 const float f = (float)(word >> 8) * (1.0f / 16777216.0f);
                 randfloat[t] = f;
-                if (t < 16) s_float_bits[t] = ((double)f < two_prob) ? 1u : 0u;
-            }
-            __syncthreads();
-            if (t == 0) {
-                uint32_t m = 0;
-                for (int c = 0; c < 16; ++c) m |= s_float_bits[c] << c;
-                two_masks[E] = m;
+                if (wave == 0) { // cells 0..15 are lanes 0..15 of wave 0
+                    const unsigned long long m = __ballot((double)f < two_prob);
+                    if (lane == 0) two_masks[E] = (uint32_t)(m & 0xFFFFull);
+                }
             }
             // cursor: used + 1024 words of the window are gone
             {
                 const uint32_t wc = used + ML2048_RAND_SIZE - (uint32_t)p0; // words taken from fresh outputs
                 const uint32_t steps = (wc + 1) / 2;
                 has32 = (int)(wc & 1u);
-                const u128 nxt = jump_ahead(cur, inc, steps, pow2);
+                // steps = 12 q + r: one table jump (2 multiplies) + r < 12 single steps
+                const uint32_t q = steps / kStepsPerThread, r = steps - q * kStepsPerThread;
+                u128 nxt = q < (uint32_t)kThreads ? ws[q].P * cur + ws[q].G * inc : jump_ahead(cur, inc, steps - r, pow2);
+                for (uint32_t z = 0; z < r; ++z) nxt = nxt * A + inc;
                 if (has32) buf32 = (uint32_t)(xsl_rr(nxt) >> 32);
                 cur = nxt;
             }
             ++E;
-            __syncthreads();
+            lds_barrier(); // the next regeneration overwrites `words`
             ML_T(t_float)
         }
         // rand_offset of prepare (:626) and of step (:670): integers(0, 1024) = next32 >> 22
@@ -344,12 +358,8 @@ __global__ __launch_bounds__(kThreads) void k_devrng_schedule(const Jump *__rest
     }
 
     // final state: table rows, generator, rand_step
-    {
-        uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int q = 0; q < 16; ++q) w[q >> 2] |= (uint32_t)rows[q][t] << (8 * (q & 3));
-        reinterpret_cast<uint4 *>(randperm)[t] = make_uint4(w[0], w[1], w[2], w[3]);
-    }
+    reinterpret_cast<uint4 *>(randperm)[t] =
+        make_uint4((uint32_t)row_lo, (uint32_t)(row_lo >> 32), (uint32_t)row_hi, (uint32_t)(row_hi >> 32));
     if (t == 0) {
         rng->state_hi = (uint64_t)(cur >> 64);
         rng->state_lo = (uint64_t)cur;
