@@ -178,6 +178,13 @@ def main():
             dist_mod.init_process_group(backend="gloo")
         dist = dist_mod
 
+    # host threads of the schedule producer: this rank's share of the box's CPUs (cgroup quota / ranks
+    # on this node), minus the Python thread and the producer itself; 6 is plenty
+    if "ML2048_HOST_THREADS" not in os.environ:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        share = max(1, host_cpu_share() // max(1, local_world))
+        os.environ["ML2048_HOST_THREADS"] = str(max(1, min(6, share - 2)))
+
     M, N, K, W = args.boards, args.env_steps, args.steps, args.warmup
     # shard `rank` of a 2-level game: independent replica with its own seed (SURVEY 8e replica mode)
     env = amd.VecGame(M, amd.reward_fn_normal, device=dev, idx_base=0, step_mapping=args.step_mapping,
