@@ -337,7 +337,8 @@ def main():
             "config": {"workload": f"C2: M={M} boards/GPU x N={N} random-action env steps per bench step "
                                    f"({'masked' if args.masked else 'unmasked'} uniform actions sampled on device, "
                                    f"table spawn = bit-exact mode), mode={args.mode}",
-                       "boards_per_gpu": M, "env_steps_per_step": N, "mode": args.mode, "sharding": f"replicas x{world}"},
+                       "boards_per_gpu": M, "env_steps_per_step": N, "mode": args.mode, "sharding": f"replicas x{world}",
+                       "host_schedule": args.schedule, "spawn": "table (bit-exact with the reference's PCG64 tables)"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         line.update(extras)
