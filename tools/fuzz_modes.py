@@ -1,0 +1,63 @@
+"""Soak test: four VecGame instances (schedule = host / host-async / device, and a per-step-only
+reference) driven through a random interleaving of fused rollouts of random lengths, per-step
+prepare/step pairs, summary()/property reads and occasional reset()s.  All four must stay
+bit-identical.  Run on the GPU box:  python tools/fuzz_modes.py [seconds]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import ml2048_amd as amd
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+M = 4099
+rng = np.random.default_rng(2048)
+kinds = ["normal", "improved", "rank", "maxcell"]
+t0 = time.time()
+rounds = ops = 0
+while time.time() - t0 < budget:
+    kind = kinds[rounds % 4]
+    envs = {m: amd.VecGame(M, kind, schedule=m) for m in ("host", "host-async", "device")}
+    step_env = amd.VecGame(M, kind)
+    pol = amd.RandomPolicy(seed=5, masked=True)
+    seed = int(rng.integers(0, 2**31))
+    for e in list(envs.values()) + [step_env]:
+        e.reset(seed)
+    counter = 0
+    for _ in range(int(rng.integers(5, 25))):
+        op = rng.integers(0, 10)
+        if op < 6:  # fused rollout of a random length
+            n = int(rng.choice([1, 2, 7, 33, 64, 128, 200]))
+            for e in envs.values():
+                e.rollout(n, masked=True, act_seed=5, act_counter=counter)
+            for _ in range(n):
+                step_env.prepare_torch()
+                pol.counter = counter
+                a, _ = pol.sample_actions_u8(step_env.valid_actions)
+                step_env.step_torch(a)
+                counter += 1
+        elif op < 8:  # per-step pair on everyone with explicit actions
+            a = rng.integers(0, 4, size=M).astype(np.uint8)
+            for e in list(envs.values()) + [step_env]:
+                e.prepare()
+                e.step(a)
+        elif op == 8:  # reads that force generator hand-backs
+            vals = {m: (e._rand_step, e._game_count) for m, e in envs.items()}
+            assert len(set(vals.values())) == 1, vals
+            assert vals["host"] == (step_env._rand_step, step_env._game_count)
+        else:
+            seed = int(rng.integers(0, 2**31))
+            counter = 0
+            for e in list(envs.values()) + [step_env]:
+                e.reset(seed)
+        ops += 1
+        ref = step_env.digest()
+        for m, e in envs.items():
+            assert e.digest() == ref, (rounds, ops, m)
+    ref = step_env._data.tobytes()
+    for m, e in envs.items():
+        assert e._data.tobytes() == ref, (rounds, m)
+    rounds += 1
+print(f"fuzz ok: {rounds} rounds, {ops} operations in {time.time()-t0:.0f}s")
