@@ -106,7 +106,8 @@ def load(path: str | None = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    # ML2048_HIP_LIB: alternative build of the same ABI (A/B experiments); the default is the in-tree library
+    p = path or os.environ.get("ML2048_HIP_LIB") or LIB_PATH
     if not os.path.exists(p):
         raise Ml2048Error(
             f"{p} not found: build the HIP extension first (python -m ml2048_amd.build). "

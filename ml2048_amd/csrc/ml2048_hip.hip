@@ -665,7 +665,10 @@ __global__ __launch_bounds__(kBlock) void k_digest(ml2048_state st, int64_t M, i
 // Global traffic per step is the 16-byte permutation row(s) (L1/L2-resident 16 KiB table), the
 // optional 1-byte action, and 8 bytes of re-deal flags per wave; state is read once and written
 // once per launch.
-template <int KIND, bool FAST>
+// EXTRAS = false compiles the optional outputs (actions_out, digests_out, trajectory) out entirely:
+// with one wave per SIMD every taken branch costs an instruction-buffer refill, and a dozen
+// "pointer is NULL, skip" branches per step were ~10 % of the kernel (SQ_WAIT_ANY, profiles/).
+template <int KIND, bool FAST, bool EXTRAS>
 __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, int64_t idx_base, int N,
                                                     const uint8_t *__restrict__ perm_epochs,
                                                     const uint32_t *__restrict__ two_masks,
@@ -676,6 +679,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                                                     uint64_t *__restrict__ reset_flags, int64_t flag_words,
                                                     int32_t *__restrict__ last_reset, uint64_t spawn_seed,
                                                     uint64_t spawn_counter0, uint64_t thr, ml2048_traj traj) {
+#ifdef ML2048_ROLLOUT_PREFETCH
+    __shared__ unsigned long long flag_park[kBlock / 64][128];
+#endif
     // The schedule kernel of the NEXT rollout (csrc/devrng.hip) may share a CU with one of these
     // workgroups; the rollout is the critical path, so its waves win the issue arbitration.
     __builtin_amdgcn_s_setprio(1);
@@ -706,9 +712,46 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
     bool merged_stale = false; // true once s.merged no longer reflects (mexp_first, mexp_second)
     uint32_t aw[4] = {0, 0, 0, 0}; // the sampler's current Philox block (4 consecutive steps)
 
+#ifdef ML2048_ROLLOUT_PREFETCH
+    // Experimental (A/B via -DML2048_ROLLOUT_PREFETCH): fetch everything that does not depend on game
+    // state one step ahead - at M = 65 536 there is one wave per SIMD and SQ_WAIT_ANY is a third of the
+    // wave's cycles (profiles/r01_i_sq_counters.json).
+    int n_epoch = 0;
+    int64_t n_row_p = 0, n_row_s = 0;
+    uint32_t n_two_mask = 0;
+    uint32_t n_perm_s[4] = {0, 0, 0, 0}, n_perm_p[4] = {0, 0, 0, 0};
+    if (!FAST) {
+        n_epoch = schedule[0];
+        n_row_p = schedule[1];
+        n_row_s = schedule[2];
+        n_two_mask = two_masks[n_epoch];
+        load_perm_row(perm_epochs + (int64_t)n_epoch * (ML2048_RAND_SIZE * 16), n_row_s + idx_base + ii, n_perm_s);
+        load_perm_row(perm_epochs + (int64_t)n_epoch * (ML2048_RAND_SIZE * 16), n_row_p + idx_base + ii, n_perm_p);
+    }
+#endif
     for (int t = 0; t < N; ++t) {
         // table mode: the pre-drawn host schedule; fast mode: rocRAND Philox words keyed
         // (spawn_seed; board; 2*(counter0+t) for the deal, +1 for the step) as the per-step API does
+#ifdef ML2048_ROLLOUT_PREFETCH
+        const int epoch = n_epoch;
+        const int64_t row_p = n_row_p, row_s = n_row_s;
+        const uint8_t *table = perm_epochs + (int64_t)epoch * (ML2048_RAND_SIZE * 16);
+        const uint32_t two_mask = n_two_mask;
+        uint32_t perm_s[4] = {n_perm_s[0], n_perm_s[1], n_perm_s[2], n_perm_s[3]};
+        uint32_t perm_p[4] = {n_perm_p[0], n_perm_p[1], n_perm_p[2], n_perm_p[3]};
+        if (!FAST && t + 1 < N) { // requests for step t+1, consumed one iteration later
+            n_epoch = schedule[3 * t + 3];
+            n_row_p = schedule[3 * t + 4];
+            n_row_s = schedule[3 * t + 5];
+            n_two_mask = two_masks[n_epoch];
+            const uint8_t *ntab = perm_epochs + (int64_t)n_epoch * (ML2048_RAND_SIZE * 16);
+            load_perm_row(ntab, n_row_s + idx_base + ii, n_perm_s);
+            load_perm_row(ntab, n_row_p + idx_base + ii, n_perm_p);
+        }
+        (void)row_s;
+        (void)row_p;
+        (void)table;
+#else
         int epoch = 0;
         int64_t row_p = 0, row_s = 0;
         const uint8_t *table = perm_epochs;
@@ -720,11 +763,23 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
             table = perm_epochs + (int64_t)epoch * (ML2048_RAND_SIZE * 16);
             two_mask = two_masks[epoch];
         }
+#endif
 
         // ---- prepare (game_numba.py:619-658)
         const bool deal = s.terminated != 0;
         const unsigned long long dealt = __ballot(deal && live);
+#ifdef ML2048_ROLLOUT_PREFETCH
+        // keep the loop free of global stores (their acknowledgement would sit in the same vmcnt queue
+        // as the prefetched loads): the re-deal flags of up to 128 steps are parked in LDS
+        if (lane == 0) flag_park[threadIdx.x >> 6][t & 127] = dealt;
+        if ((t & 127) == 127 || t == N - 1) {
+            const int t0 = t & ~127;
+            for (int q = lane; q <= (t & 127); q += 64)
+                reset_flags[(int64_t)(t0 + q) * flag_words + wave_global] = flag_park[threadIdx.x >> 6][q];
+        }
+#else
         if (lane == 0) reset_flags[(int64_t)t * flag_words + wave_global] = dealt;
+#endif
         if (deal) {
             clear_regs(s);
             invalid = 0;
@@ -736,9 +791,13 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                 spawn_counter(s.board, w4[0], w4[1], thr);
                 spawn_counter(s.board, w4[2], w4[3], thr);
             } else {
+#ifdef ML2048_ROLLOUT_PREFETCH
+                deal_table(s.board, perm_p, two_mask);
+#else
                 uint32_t perm[4];
                 load_perm_row(table, row_p + idx_base + ii, perm);
                 deal_table(s.board, perm, two_mask);
+#endif
             }
             s.valid = valid_actions(s.board);
             last = t;
@@ -755,7 +814,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
         const uint32_t word = k4 == 0 ? aw[0] : k4 == 1 ? aw[1] : k4 == 2 ? aw[2] : aw[3];
         uint32_t cnt;
         const uint32_t action = pick_action(masked ? s.valid : 0x01010101u, word, masked, cnt);
-        if (actions_out && live) actions_out[(int64_t)t * M + i] = (uint8_t)action;
+        if (EXTRAS && actions_out && live) actions_out[(int64_t)t * M + i] = (uint8_t)action;
         // ---- step (game_numba.py:660-738)
         prev_board = s.board;
         prev_valid = s.valid;
@@ -766,9 +825,13 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                 rocrand_words(spawn_seed, 2ull * (spawn_counter0 + (uint64_t)t) + 1ull, (uint64_t)(idx_base + ii), w4);
                 spawn_counter(s.board, w4[0], w4[1], thr);
             } else {
+#ifdef ML2048_ROLLOUT_PREFETCH
+                spawn_table(s.board, perm_s, two_mask, 1);
+#else
                 uint32_t perm[4];
                 load_perm_row(table, row_s + idx_base + ii, perm);
                 spawn_table(s.board, perm, two_mask, 1);
+#endif
             }
             step_post(s);
             invalid = 0;
@@ -777,7 +840,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
         }
         // ---- optional trajectory: this step's transition into [N][M] buffers with the REPLAY_SPEC
         //      dtypes (replay.py:10-20), i.e. what N x ml2048_record_transition would write
-        if (live) {
+        if (EXTRAS && live) {
             const int64_t o = (int64_t)t * M + i;
             if (traj.state) reinterpret_cast<uint4 *>(traj.state)[o] = make_uint4(prev_board.r[0], prev_board.r[1], prev_board.r[2], prev_board.r[3]);
             if (traj.next_state) reinterpret_cast<uint4 *>(traj.next_state)[o] = make_uint4(s.board.r[0], s.board.r[1], s.board.r[2], s.board.r[3]);
@@ -789,7 +852,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
             if (traj.step) traj.step[o] = s.step;
             if (traj.terminated) traj.terminated[o] = s.terminated != 0;
         }
-        if (digests_out) {
+        if (EXTRAS && digests_out) {
             if (merged_stale) {
                 merge_buckets(mexp_first, mexp_second, s.merged);
                 merged_stale = false;
@@ -1145,10 +1208,17 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
     const dim3 grid((unsigned)cdiv(M, kBlock)), block(kBlock);
     const int64_t W = ml2048_rollout_flag_words(M);
     const uint64_t thr = two_threshold(two_prob);
-#define ML_LAUNCH(K, F)                                                                                      \
-    hipLaunchKernelGGL((k_rollout<K, F>), grid, block, 0, s, *st, M, idx_base, N, perm_epochs, two_masks,   \
+    const bool extras = actions_out || digests_out || traj_or_null;
+#define ML_LAUNCH2(K, F, X)                                                                                  \
+    hipLaunchKernelGGL((k_rollout<K, F, X>), grid, block, 0, s, *st, M, idx_base, N, perm_epochs, two_masks, \
                        schedule, masked, act_seed, act_counter0, actions_out, digests_out, reset_flags, W,  \
                        last_reset, spawn_seed, spawn_counter0, thr, traj)
+#define ML_LAUNCH(K, F)          \
+    if (extras) {                \
+        ML_LAUNCH2(K, F, true);  \
+    } else {                     \
+        ML_LAUNCH2(K, F, false); \
+    }
 #define ML_KIND(F)                                                                   \
     switch (reward_kind) {                                                           \
     case ML2048_REWARD_NORMAL: ML_LAUNCH(REWARD_NORMAL, F); break;                   \
@@ -1164,6 +1234,7 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
     }
 #undef ML_KIND
 #undef ML_LAUNCH
+#undef ML_LAUNCH2
     return check_launch("ml2048_rollout");
 }
 
