@@ -34,7 +34,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     for src in HOST_SOURCES:
         obj = os.path.splitext(src)[0] + ".o"
-        cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-fopenmp", "-pthread", "-c", src, "-o", obj]
+        cmd = [os.environ.get("CXX", "g++"), "-O2", "-mssse3", "-std=c++17", "-fPIC", "-fopenmp", "-pthread", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

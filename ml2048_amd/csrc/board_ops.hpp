@@ -442,17 +442,16 @@ ML_HD uint32_t sampler_word(uint64_t seed, uint64_t t, uint64_t idx) {
 
 // masked-uniform / uniform action from one random word (oracle orc_sample_actions)
 ML_HD uint32_t pick_action(uint32_t valid_word, uint32_t word, int masked, uint32_t &cnt_out) {
-    if (!masked) {
-        cnt_out = 4;
-        return word & 3u;
-    }
+    // branch-free on purpose: in the fused rollout a taken branch costs an instruction-buffer refill
     uint32_t bits = flags4(nz_bytes(valid_word));
-    uint32_t cnt = (uint32_t)__builtin_popcount(bits);
-    cnt_out = cnt;
-    if (cnt == 0) return 0;
-    uint32_t k = (uint32_t)(((uint64_t)word * cnt) >> 32);
-    for (uint32_t j = 0; j < k; ++j) bits &= bits - 1u;
-    return (uint32_t)__builtin_ctz(bits);
+    const uint32_t cnt = (uint32_t)__builtin_popcount(bits);
+    const uint32_t k = (uint32_t)(((uint64_t)word * cnt) >> 32);
+    bits = k > 0 ? bits & (bits - 1u) : bits; // drop the k lowest set bits
+    bits = k > 1 ? bits & (bits - 1u) : bits;
+    bits = k > 2 ? bits & (bits - 1u) : bits;
+    const uint32_t kth = bits ? (uint32_t)__builtin_ctz(bits) : 0u; // cnt == 0 -> action 0
+    cnt_out = masked ? cnt : 4u;
+    return masked ? kth : (word & 3u);
 }
 
 ML_HD float neg_log_count(uint32_t cnt) {

@@ -37,6 +37,7 @@ int check_launch(const char *what) {
 }
 
 constexpr int kBlock = 256;      // threads per workgroup for the per-board kernels (4 waves)
+constexpr int kFlagChunk = 128;  // rollout steps whose re-deal flags are parked in LDS between flushes
 constexpr int kPrepBlock = 1024; // boards per workgroup in the prepare scan
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -87,6 +88,11 @@ __device__ __forceinline__ uint32_t two_mask_from_table(const float *randfloat, 
 __device__ __forceinline__ void load_perm_row(const uint8_t *randperm, int64_t row, uint32_t perm[4]) {
     uint4 v = reinterpret_cast<const uint4 *>(randperm)[row & (ML2048_RAND_SIZE - 1)];
     perm[0] = v.x; perm[1] = v.y; perm[2] = v.z; perm[3] = v.w;
+}
+
+// first four cells of a permutation row (the re-deal reads two: board_ops.hpp deal_table)
+__device__ __forceinline__ uint32_t load_perm_head(const uint8_t *randperm, int64_t row) {
+    return reinterpret_cast<const uint32_t *>(randperm)[(row & (ML2048_RAND_SIZE - 1)) * 4];
 }
 
 // rocRAND Philox4x32-10 device generator: words of (seed, subsequence = idx, offset = 4*counter)
@@ -672,16 +678,16 @@ template <int KIND, bool FAST, bool EXTRAS>
 __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, int64_t idx_base, int N,
                                                     const uint8_t *__restrict__ perm_epochs,
                                                     const uint32_t *__restrict__ two_masks,
-                                                    const int32_t *__restrict__ schedule, int masked,
-                                                    uint64_t act_seed, uint64_t act_counter0,
+                                                    const int32_t *__restrict__ schedule, int n_epochs,
+                                                    int masked, uint64_t act_seed, uint64_t act_counter0,
                                                     uint8_t *__restrict__ actions_out,
                                                     uint64_t *__restrict__ digests_out,
                                                     uint64_t *__restrict__ reset_flags, int64_t flag_words,
                                                     int32_t *__restrict__ last_reset, uint64_t spawn_seed,
                                                     uint64_t spawn_counter0, uint64_t thr, ml2048_traj traj) {
-#ifdef ML2048_ROLLOUT_PREFETCH
-    __shared__ unsigned long long flag_park[kBlock / 64][128];
-#endif
+    // re-deal flags of up to kFlagChunk steps are parked in LDS so that the step loop holds no global
+    // store (its acknowledgement would share the vmcnt queue with the prefetched loads)
+    __shared__ unsigned long long flag_park[kBlock / 64][kFlagChunk];
     // The schedule kernel of the NEXT rollout (csrc/devrng.hip) may share a CU with one of these
     // workgroups; the rollout is the critical path, so its waves win the issue arbitration.
     __builtin_amdgcn_s_setprio(1);
@@ -710,160 +716,148 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
     // the loop carries the <= 8 merge exponents of the last valid move and expands them lazily.
     uint32_t mexp_first = 0, mexp_second = 0;
     bool merged_stale = false; // true once s.merged no longer reflects (mexp_first, mexp_second)
-    uint32_t aw[4] = {0, 0, 0, 0}; // the sampler's current Philox block (4 consecutive steps)
-
-#ifdef ML2048_ROLLOUT_PREFETCH
-    // Experimental (A/B via -DML2048_ROLLOUT_PREFETCH): fetch everything that does not depend on game
-    // state one step ahead - at M = 65 536 there is one wave per SIMD and SQ_WAIT_ANY is a third of the
-    // wave's cycles (profiles/r01_i_sq_counters.json).
-    int n_epoch = 0;
-    int64_t n_row_p = 0, n_row_s = 0;
-    uint32_t n_two_mask = 0;
-    uint32_t n_perm_s[4] = {0, 0, 0, 0}, n_perm_p[4] = {0, 0, 0, 0};
-    if (!FAST) {
-        n_epoch = schedule[0];
-        n_row_p = schedule[1];
-        n_row_s = schedule[2];
-        n_two_mask = two_masks[n_epoch];
-        load_perm_row(perm_epochs + (int64_t)n_epoch * (ML2048_RAND_SIZE * 16), n_row_s + idx_base + ii, n_perm_s);
-        load_perm_row(perm_epochs + (int64_t)n_epoch * (ML2048_RAND_SIZE * 16), n_row_p + idx_base + ii, n_perm_p);
+    // The sampler's Philox block serves 4 consecutive counters; aw[0] is always the current step's word.
+    uint32_t aw[4];
+    {
+        rocrand_state_philox4x32_10 rs;
+        rocrand_init(act_seed, (uint64_t)(idx_base + ii), act_counter0 & ~3ull, &rs);
+        const uint4 v = rocrand4(&rs);
+        aw[0] = v.x; aw[1] = v.y; aw[2] = v.z; aw[3] = v.w;
+        for (uint32_t q = 0; q < (uint32_t)(act_counter0 & 3ull); ++q) { // wave-uniform, outside the loop
+            aw[0] = aw[1]; aw[1] = aw[2]; aw[2] = aw[3];
+        }
     }
-#endif
-    for (int t = 0; t < N; ++t) {
-        // table mode: the pre-drawn host schedule; fast mode: rocRAND Philox words keyed
-        // (spawn_seed; board; 2*(counter0+t) for the deal, +1 for the step) as the per-step API does
-#ifdef ML2048_ROLLOUT_PREFETCH
-        const int epoch = n_epoch;
-        const int64_t row_p = n_row_p, row_s = n_row_s;
-        const uint8_t *table = perm_epochs + (int64_t)epoch * (ML2048_RAND_SIZE * 16);
-        const uint32_t two_mask = n_two_mask;
-        uint32_t perm_s[4] = {n_perm_s[0], n_perm_s[1], n_perm_s[2], n_perm_s[3]};
-        uint32_t perm_p[4] = {n_perm_p[0], n_perm_p[1], n_perm_p[2], n_perm_p[3]};
-        if (!FAST && t + 1 < N) { // requests for step t+1, consumed one iteration later
-            n_epoch = schedule[3 * t + 3];
-            n_row_p = schedule[3 * t + 4];
-            n_row_s = schedule[3 * t + 5];
-            n_two_mask = two_masks[n_epoch];
-            const uint8_t *ntab = perm_epochs + (int64_t)n_epoch * (ML2048_RAND_SIZE * 16);
-            load_perm_row(ntab, n_row_s + idx_base + ii, n_perm_s);
-            load_perm_row(ntab, n_row_p + idx_base + ii, n_perm_p);
-        }
-        (void)row_s;
-        (void)row_p;
-        (void)table;
-#else
-        int epoch = 0;
-        int64_t row_p = 0, row_s = 0;
-        const uint8_t *table = perm_epochs;
-        uint32_t two_mask = 0;
-        if (!FAST) {
-            epoch = schedule[3 * t + 0];
-            row_p = schedule[3 * t + 1];
-            row_s = schedule[3 * t + 2];
-            table = perm_epochs + (int64_t)epoch * (ML2048_RAND_SIZE * 16);
-            two_mask = two_masks[epoch];
-        }
-#endif
 
-        // ---- prepare (game_numba.py:619-658)
-        const bool deal = s.terminated != 0;
-        const unsigned long long dealt = __ballot(deal && live);
-#ifdef ML2048_ROLLOUT_PREFETCH
-        // keep the loop free of global stores (their acknowledgement would sit in the same vmcnt queue
-        // as the prefetched loads): the re-deal flags of up to 128 steps are parked in LDS
-        if (lane == 0) flag_park[threadIdx.x >> 6][t & 127] = dealt;
-        if ((t & 127) == 127 || t == N - 1) {
-            const int t0 = t & ~127;
-            for (int q = lane; q <= (t & 127); q += 64)
-                reset_flags[(int64_t)(t0 + q) * flag_words + wave_global] = flag_park[threadIdx.x >> 6][q];
-        }
-#else
-        if (lane == 0) reset_flags[(int64_t)t * flag_words + wave_global] = dealt;
-#endif
-        if (deal) {
-            clear_regs(s);
-            invalid = 0;
-            mexp_first = mexp_second = 0;
-            merged_stale = true;
-            if (FAST) {
-                uint32_t w4[4];
-                rocrand_words(spawn_seed, 2ull * (spawn_counter0 + (uint64_t)t), (uint64_t)(idx_base + ii), w4);
-                spawn_counter(s.board, w4[0], w4[1], thr);
-                spawn_counter(s.board, w4[2], w4[3], thr);
+    // Everything that does not depend on game state is fetched ahead of its use - at M = 65 536 there is
+    // one wave per SIMD and nobody else to hide a load behind (profiles/r01_i_sq_counters.json): the
+    // schedule entry (scalar loads) two steps ahead, the two-mask and both permutation rows one step
+    // ahead.  The re-deal only reads the first two cells of its row, so that load is a single dword
+    // (a dwordx4 with three dead result registers makes the compiler wait for the load mid-step before
+    // it can reuse them).  Indices are clamped instead of branched around at the end of the schedule.
+    int e1 = 0;
+    int64_t rp1 = 0, rs1 = 0;           // schedule entry of step t+1
+    uint32_t n_two_mask = 0, n_perm_p = 0; // data of step t, in flight since the previous iteration
+    uint32_t n_perm_s[4] = {0, 0, 0, 0};
+    // an epoch index is clamped to the tables that exist: a corrupted schedule then yields wrong
+    // boards, never an out-of-bounds read (rows are already taken modulo the table size)
+    const uint32_t e_last = (uint32_t)(n_epochs - 1);
+    if (!FAST) {
+        const uint32_t e0r = (uint32_t)schedule[0];
+        const int e0 = (int)(e0r < e_last ? e0r : e_last);
+        const uint8_t *tab0 = perm_epochs + (int64_t)e0 * (ML2048_RAND_SIZE * 16);
+        n_two_mask = two_masks[e0];
+        n_perm_p = load_perm_head(tab0, (int64_t)schedule[1] + idx_base + ii);
+        load_perm_row(tab0, (int64_t)schedule[2] + idx_base + ii, n_perm_s);
+        const int j1 = N > 1 ? 1 : 0;
+        const uint32_t e1r = (uint32_t)schedule[3 * j1 + 0];
+        e1 = (int)(e1r < e_last ? e1r : e_last);
+        rp1 = schedule[3 * j1 + 1];
+        rs1 = schedule[3 * j1 + 2];
+    }
+    for (int t0 = 0; t0 < N; t0 += kFlagChunk) {
+        const int t1 = t0 + kFlagChunk < N ? t0 + kFlagChunk : N;
+        for (int t = t0; t < t1; ++t) {
+            // table mode: the pre-drawn host schedule; fast mode: rocRAND Philox words keyed
+            // (spawn_seed; board; 2*(counter0+t) for the deal, +1 for the step) as the per-step API does
+            const uint32_t two_mask = n_two_mask;
+            const uint32_t perm_p = n_perm_p;
+            const uint32_t perm_s[4] = {n_perm_s[0], n_perm_s[1], n_perm_s[2], n_perm_s[3]};
+            if (!FAST) {
+                const uint8_t *tab1 = perm_epochs + (int64_t)e1 * (ML2048_RAND_SIZE * 16);
+                n_two_mask = two_masks[e1];
+                n_perm_p = load_perm_head(tab1, rp1 + idx_base + ii);
+                load_perm_row(tab1, rs1 + idx_base + ii, n_perm_s);
+                const int j2 = t + 2 < N ? t + 2 : N - 1;
+                const uint32_t e2r = (uint32_t)schedule[3 * j2 + 0];
+                e1 = (int)(e2r < e_last ? e2r : e_last);
+                rp1 = schedule[3 * j2 + 1];
+                rs1 = schedule[3 * j2 + 2];
+            }
+
+            // ---- prepare (game_numba.py:619-658)
+            const bool deal = s.terminated != 0;
+            const unsigned long long dealt = __ballot(deal && live);
+            if (lane == 0) flag_park[threadIdx.x >> 6][t - t0] = dealt;
+            if (deal) {
+                clear_regs(s);
+                invalid = 0;
+                mexp_first = mexp_second = 0;
+                merged_stale = true;
+                if (FAST) {
+                    uint32_t w4[4];
+                    rocrand_words(spawn_seed, 2ull * (spawn_counter0 + (uint64_t)t), (uint64_t)(idx_base + ii), w4);
+                    spawn_counter(s.board, w4[0], w4[1], thr);
+                    spawn_counter(s.board, w4[2], w4[3], thr);
+                } else {
+                    const uint32_t head[4] = {perm_p, 0, 0, 0};
+                    deal_table(s.board, head, two_mask);
+                }
+                s.valid = valid_actions(s.board);
+                last = t;
+            }
+            // ---- sample (policy/random.py:17-27)
+            const uint64_t tt = act_counter0 + (uint64_t)t;
+            if (t > 0 && (tt & 3ull) == 0) {
+                rocrand_state_philox4x32_10 rs;
+                rocrand_init(act_seed, (uint64_t)(idx_base + ii), tt, &rs);
+                const uint4 v = rocrand4(&rs);
+                aw[0] = v.x; aw[1] = v.y; aw[2] = v.z; aw[3] = v.w;
+            }
+            const uint32_t word = aw[0];
+            aw[0] = aw[1]; aw[1] = aw[2]; aw[2] = aw[3];
+            uint32_t cnt;
+            const uint32_t action = pick_action(s.valid, word, masked, cnt);
+            if (EXTRAS && actions_out && live) actions_out[(int64_t)t * M + i] = (uint8_t)action;
+            // ---- step (game_numba.py:660-738)
+            prev_board = s.board;
+            prev_valid = s.valid;
+            if (step_pre_lite(s, action, KIND, mexp_first, mexp_second)) {
+                merged_stale = true;
+                if (FAST) {
+                    uint32_t w4[4];
+                    rocrand_words(spawn_seed, 2ull * (spawn_counter0 + (uint64_t)t) + 1ull, (uint64_t)(idx_base + ii), w4);
+                    spawn_counter(s.board, w4[0], w4[1], thr);
+                } else {
+                    spawn_table(s.board, perm_s, two_mask, 1);
+                }
+                step_post(s);
+                invalid = 0;
             } else {
-#ifdef ML2048_ROLLOUT_PREFETCH
-                deal_table(s.board, perm_p, two_mask);
-#else
-                uint32_t perm[4];
-                load_perm_row(table, row_p + idx_base + ii, perm);
-                deal_table(s.board, perm, two_mask);
-#endif
+                invalid = 1;
             }
-            s.valid = valid_actions(s.board);
-            last = t;
-        }
-        // ---- sample (policy/random.py:17-27): one Philox block serves 4 consecutive steps
-        const uint64_t tt = act_counter0 + (uint64_t)t;
-        if (t == 0 || (tt & 3ull) == 0) {
-            rocrand_state_philox4x32_10 rs;
-            rocrand_init(act_seed, (uint64_t)(idx_base + ii), tt & ~3ull, &rs);
-            const uint4 v = rocrand4(&rs);
-            aw[0] = v.x; aw[1] = v.y; aw[2] = v.z; aw[3] = v.w;
-        }
-        const uint32_t k4 = (uint32_t)(tt & 3ull); // wave-uniform
-        const uint32_t word = k4 == 0 ? aw[0] : k4 == 1 ? aw[1] : k4 == 2 ? aw[2] : aw[3];
-        uint32_t cnt;
-        const uint32_t action = pick_action(masked ? s.valid : 0x01010101u, word, masked, cnt);
-        if (EXTRAS && actions_out && live) actions_out[(int64_t)t * M + i] = (uint8_t)action;
-        // ---- step (game_numba.py:660-738)
-        prev_board = s.board;
-        prev_valid = s.valid;
-        if (step_pre_lite(s, action, KIND, mexp_first, mexp_second)) {
-            merged_stale = true;
-            if (FAST) {
-                uint32_t w4[4];
-                rocrand_words(spawn_seed, 2ull * (spawn_counter0 + (uint64_t)t) + 1ull, (uint64_t)(idx_base + ii), w4);
-                spawn_counter(s.board, w4[0], w4[1], thr);
-            } else {
-#ifdef ML2048_ROLLOUT_PREFETCH
-                spawn_table(s.board, perm_s, two_mask, 1);
-#else
-                uint32_t perm[4];
-                load_perm_row(table, row_s + idx_base + ii, perm);
-                spawn_table(s.board, perm, two_mask, 1);
-#endif
+            // ---- optional trajectory: this step's transition into [N][M] buffers with the REPLAY_SPEC
+            //      dtypes (replay.py:10-20), i.e. what N x ml2048_record_transition would write
+            if (EXTRAS && live) {
+                const int64_t o = (int64_t)t * M + i;
+                if (traj.state) reinterpret_cast<uint4 *>(traj.state)[o] = make_uint4(prev_board.r[0], prev_board.r[1], prev_board.r[2], prev_board.r[3]);
+                if (traj.next_state) reinterpret_cast<uint4 *>(traj.next_state)[o] = make_uint4(s.board.r[0], s.board.r[1], s.board.r[2], s.board.r[3]);
+                if (traj.valid_actions) reinterpret_cast<uint32_t *>(traj.valid_actions)[o] = prev_valid;
+                if (traj.next_valid_actions) reinterpret_cast<uint32_t *>(traj.next_valid_actions)[o] = s.valid;
+                if (traj.action) traj.action[o] = (int8_t)action;
+                if (traj.action_log_prob) traj.action_log_prob[o] = neg_log_count(cnt);
+                if (traj.reward) traj.reward[o] = s.reward;
+                if (traj.step) traj.step[o] = s.step;
+                if (traj.terminated) traj.terminated[o] = s.terminated != 0;
             }
-            step_post(s);
-            invalid = 0;
-        } else {
-            invalid = 1;
-        }
-        // ---- optional trajectory: this step's transition into [N][M] buffers with the REPLAY_SPEC
-        //      dtypes (replay.py:10-20), i.e. what N x ml2048_record_transition would write
-        if (EXTRAS && live) {
-            const int64_t o = (int64_t)t * M + i;
-            if (traj.state) reinterpret_cast<uint4 *>(traj.state)[o] = make_uint4(prev_board.r[0], prev_board.r[1], prev_board.r[2], prev_board.r[3]);
-            if (traj.next_state) reinterpret_cast<uint4 *>(traj.next_state)[o] = make_uint4(s.board.r[0], s.board.r[1], s.board.r[2], s.board.r[3]);
-            if (traj.valid_actions) reinterpret_cast<uint32_t *>(traj.valid_actions)[o] = prev_valid;
-            if (traj.next_valid_actions) reinterpret_cast<uint32_t *>(traj.next_valid_actions)[o] = s.valid;
-            if (traj.action) traj.action[o] = (int8_t)action;
-            if (traj.action_log_prob) traj.action_log_prob[o] = neg_log_count(cnt);
-            if (traj.reward) traj.reward[o] = s.reward;
-            if (traj.step) traj.step[o] = s.step;
-            if (traj.terminated) traj.terminated[o] = s.terminated != 0;
-        }
-        if (EXTRAS && digests_out) {
-            if (merged_stale) {
-                merge_buckets(mexp_first, mexp_second, s.merged);
-                merged_stale = false;
+            if (EXTRAS && digests_out) {
+                if (merged_stale) {
+                    merge_buckets(mexp_first, mexp_second, s.merged);
+                    merged_stale = false;
+                }
+                uint64_t h = 0;
+                if (live)
+                    h = board_digest((uint64_t)(idx_base + i), s.board, s.merged, s.valid, s.terminated, invalid,
+                                     s.step, 0, __float_as_uint(s.score), __float_as_uint(s.reward), 0);
+                h = wave_sum_u64(h);
+                if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(digests_out + t), (unsigned long long)h);
             }
-            uint64_t h = 0;
-            if (live)
-                h = board_digest((uint64_t)(idx_base + i), s.board, s.merged, s.valid, s.terminated, invalid,
-                                 s.step, 0, __float_as_uint(s.score), __float_as_uint(s.reward), 0);
-            h = wave_sum_u64(h);
-            if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(digests_out + t), (unsigned long long)h);
         }
+        // flush this chunk's re-deal flags (wave-private LDS row: a wave-scope fence is enough)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int q = lane; q < t1 - t0; q += 64)
+            reset_flags[(int64_t)(t0 + q) * flag_words + wave_global] = flag_park[threadIdx.x >> 6][q];
     }
     if (merged_stale) merge_buckets(mexp_first, mexp_second, s.merged);
 
@@ -1192,7 +1186,7 @@ int64_t ml2048_rollout_scratch_ints(int64_t M, int32_t N) {
 }
 
 static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
-                          const uint8_t *perm_epochs, const uint32_t *two_masks, const int32_t *schedule,
+                          const uint8_t *perm_epochs, const uint32_t *two_masks, const int32_t *schedule, int32_t n_epochs,
                           int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0, uint8_t *actions_out,
                           uint64_t *digests_out, uint64_t *reset_flags, int32_t *last_reset, uint64_t spawn_seed,
                           uint64_t spawn_counter0, double two_prob, const ml2048_traj *traj_or_null) {
@@ -1211,7 +1205,8 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
     const bool extras = actions_out || digests_out || traj_or_null;
 #define ML_LAUNCH2(K, F, X)                                                                                  \
     hipLaunchKernelGGL((k_rollout<K, F, X>), grid, block, 0, s, *st, M, idx_base, N, perm_epochs, two_masks, \
-                       schedule, masked, act_seed, act_counter0, actions_out, digests_out, reset_flags, W,  \
+                       schedule, n_epochs, masked, act_seed, act_counter0, actions_out, digests_out,         \
+                       reset_flags, W,                                                                       \
                        last_reset, spawn_seed, spawn_counter0, thr, traj)
 #define ML_LAUNCH(K, F)          \
     if (extras) {                \
@@ -1248,7 +1243,7 @@ int ml2048_rollout(void *stream, int64_t M, int64_t idx_base, const ml2048_state
         return fail(ML2048_E_INVALID, "perm_epochs/two_masks/schedule/reset_flags/last_reset is NULL");
     if ((uintptr_t)perm_epochs % 16) return fail(ML2048_E_ALIGN, "perm_epochs must be 16-byte aligned");
     if (idx_base < 0) return fail(ML2048_E_INVALID, "idx_base must be >= 0");
-    return launch_rollout((hipStream_t)stream, false, M, idx_base, st, N, perm_epochs, two_masks, schedule, reward_kind,
+    return launch_rollout((hipStream_t)stream, false, M, idx_base, st, N, perm_epochs, two_masks, schedule, n_epochs, reward_kind,
                           masked, act_seed, act_counter0, actions_out, digests_out, reset_flags, last_reset, 0, 0, 0.0,
                           nullptr);
 }
@@ -1263,7 +1258,7 @@ int ml2048_rollout_traj(void *stream, int64_t M, int64_t idx_base, const ml2048_
         return fail(ML2048_E_INVALID, "perm_epochs/two_masks/schedule/reset_flags/last_reset/traj is NULL");
     if ((uintptr_t)perm_epochs % 16) return fail(ML2048_E_ALIGN, "perm_epochs must be 16-byte aligned");
     if (idx_base < 0) return fail(ML2048_E_INVALID, "idx_base must be >= 0");
-    return launch_rollout((hipStream_t)stream, false, M, idx_base, st, N, perm_epochs, two_masks, schedule, reward_kind,
+    return launch_rollout((hipStream_t)stream, false, M, idx_base, st, N, perm_epochs, two_masks, schedule, n_epochs, reward_kind,
                           masked, act_seed, act_counter0, nullptr, nullptr, reset_flags, last_reset, 0, 0, 0.0, traj);
 }
 
@@ -1275,7 +1270,7 @@ int ml2048_rollout_fast(void *stream, int64_t M, int64_t idx_base, const ml2048_
     if (N <= 0) return fail(ML2048_E_INVALID, "N=%d must be positive", N);
     if (!reset_flags || !last_reset) return fail(ML2048_E_INVALID, "reset_flags/last_reset is NULL");
     if (idx_base < 0) return fail(ML2048_E_INVALID, "idx_base must be >= 0");
-    return launch_rollout((hipStream_t)stream, true, M, idx_base, st, N, nullptr, nullptr, nullptr, reward_kind, masked,
+    return launch_rollout((hipStream_t)stream, true, M, idx_base, st, N, nullptr, nullptr, nullptr, 1, reward_kind, masked,
                           act_seed, act_counter0, actions_out, digests_out, reset_flags, last_reset, spawn_seed,
                           spawn_counter0, two_prob, nullptr);
 }

@@ -187,6 +187,9 @@ class VecGame:
         self._schedule_mode = schedule
         self._sstream = None        # ml2048_sched_stream handle
         self._sstream_n = 0
+        self._stage = [None, None, None]  # schedule upload ring: [pinned, device, copied_ev, consumed_ev]
+        self._stage_i = 0
+        self._copy_stream = None
         self._sstream_after = None  # generator / counter / tables after the last CONSUMED schedule
         self._rng_on_device = False  # True while the device copy of the generator is the current one
         if step_mapping not in ("lane", "wave"):
@@ -296,6 +299,41 @@ class VecGame:
             self._rng.randperm[...] = perm
             self._rng.randfloat[...] = flt
             self._tables_dirty = True
+
+    def _stage_slot(self, nbytes: int):
+        """Next slot of the schedule upload ring, its pinned buffer safe to overwrite."""
+        i = self._stage_i
+        self._stage_i = (i + 1) % len(self._stage)
+        slot = self._stage[i]
+        if slot is None or slot[0].numel() < nbytes:
+            if slot is not None:
+                torch.cuda.synchronize(self.device)  # rare (a schedule with unusually many epochs)
+            cap = max(2 * nbytes, 1 << 19)
+            slot = [torch.empty((cap,), dtype=torch.uint8, pin_memory=True),
+                    torch.empty((cap,), dtype=torch.uint8, device=self.device),
+                    torch.cuda.Event(), torch.cuda.Event()]
+            self._stage[i] = slot
+            # The caching allocator hands out blocks whose previous uses are ordered on the CURRENT
+            # stream only; the copy stream writes this one, so it must first catch up with everything
+            # queued there (a block freed by another env may still be awaiting a queued kernel).
+            if self._copy_stream is None:
+                self._copy_stream = torch.cuda.Stream(device=self.device)
+            self._copy_stream.wait_stream(torch.cuda.current_stream(self.device))
+        else:
+            slot[2].synchronize()  # the copy that last read the pinned buffer (3 rollouts ago)
+        return slot
+
+    def _stage_upload(self, slot, nbytes: int):
+        dev = self.device
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(slot[3])  # the rollout that last read the device buffer
+            slot[1][:nbytes].copy_(slot[0][:nbytes], non_blocking=True)
+            slot[2].record(self._copy_stream)
+        cur.wait_event(slot[2])
+        return slot[1]
 
     def _next_schedule_async(self, N: int):
         L = self._L
@@ -591,6 +629,10 @@ class VecGame:
         self._push_rng()
         cap = N + 1  # one epoch per step at most: can never overflow
         if self._sched_slots is None or self._sched_slots[0] != N:
+            if self._sched_slots is not None and self._sched_stream is not None:
+                for old in self._sched_slots[1]:  # written on the side stream: reuse only after it is done
+                    for key in ("perm", "sched", "mask", "ne"):
+                        old[key].record_stream(self._sched_stream)
             slots = []
             for _ in range(2):  # double-buffered outputs
                 slots.append({
@@ -661,20 +703,24 @@ class VecGame:
                 # start drawing the NEXT schedule right away: it then overlaps this call's packing,
                 # upload and launches as well as the GPU work
                 self._start_prefetch(N)
-            # one packed H2D copy: [epoch tables | schedule | masks], each section 16-byte aligned
+            # one packed H2D copy: [epoch tables | schedule | masks], each section 16-byte aligned,
+            # from pinned memory on a side stream so that neither the host nor the copy waits for the
+            # previous rollout's kernels (a pageable copy on the launch stream did both: ~55 us of idle
+            # GPU per rollout at C2)
             E = epochs.shape[0]
             o_sched = E * RAND_SIZE * 16
             o_mask = o_sched + ((N * 12 + 15) // 16) * 16
-            packed = np.empty((o_mask + E * 4,), dtype=np.uint8)
+            slot = self._stage_slot(o_mask + E * 4)
+            packed = slot[0].numpy()
             packed[:o_sched] = epochs.reshape(-1)
             packed[o_sched:o_sched + N * 12] = sched.view(np.uint8).reshape(-1)
-            packed[o_mask:] = masks.view(np.uint8)
-            packed_dev = torch.from_numpy(packed).to(dev)
+            packed[o_mask:o_mask + E * 4] = masks.view(np.uint8)
             if self._schedule_mode == "host-async":
                 _lib.check(L.ml2048_sched_stream_release(self._sstream), "sched_stream_release")
+            packed_dev = self._stage_upload(slot, o_mask + E * 4)
             perm_dev = packed_dev[:o_sched]
             sched_dev = packed_dev[o_sched:o_sched + N * 12]
-            mask_dev = packed_dev[o_mask:]
+            mask_dev = packed_dev[o_mask:o_mask + E * 4]
             if E > 1:
                 self._tables_dirty = True  # device copies of the tables are refreshed lazily (per-step API)
 
@@ -723,6 +769,8 @@ class VecGame:
                     self._sched_pending_slot["free"] = ev
             if kernel_events is not None:
                 kernel_events[1].record(torch.cuda.current_stream(dev))
+            if not fast and not on_device:  # the staging slot may be refilled once this launch has read it
+                slot[3].record(torch.cuda.current_stream(dev))
             step_resets = None
             if finish_ids:
                 step_resets = torch.empty((N,), dtype=torch.int32, device=dev)
