@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary stepwise measurement")
+    ap.add_argument("--event-every", type=int, default=8,
+                    help="bracket every k-th timed launch of the dominant kernel with HIP events (the pair of "
+                         "timestamp packets costs a few us of GPU idle per launch, so not every launch carries one)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the barrier / max-over-ranks (nccl = RCCL; gloo only for "
                          "rehearsing the N>1 launch contract on a box with fewer GPUs than ranks)")
@@ -227,8 +230,8 @@ def main():
         bench_step(False)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(K):
-        bench_step(True)
+    for k in range(K):
+        bench_step(k % max(1, args.event_every) == 0)
     barrier()
     dt = time.perf_counter() - t0
     from ml2048_amd.shard import max_over_ranks

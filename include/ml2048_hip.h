@@ -255,6 +255,16 @@ int ml2048_devrng_schedule(void *stream, const void *workspace, ml2048_devrng *r
  */
 int64_t ml2048_rollout_flag_words(int64_t M);
 int64_t ml2048_rollout_scratch_ints(int64_t M, int32_t N);
+
+/*
+ * Upload of a pre-drawn schedule: a copy KERNEL that reads device-accessible (pinned / registered)
+ * host memory directly, so that the upload is an ordinary launch on `stream` (typically a side
+ * stream, overlapped with the previous rollout) and involves neither the copy engine nor a host
+ * wait.  dst: device, src_host: pinned host memory, both 16-byte aligned; nbytes is rounded up
+ * to a multiple of 16 (both buffers must have that capacity).  The reference performs no such
+ * copy: its tables never leave host memory (game_numba.py:589-591).
+ */
+int ml2048_upload(void *stream, void *dst, const void *src_host, int64_t nbytes);
 int ml2048_rollout(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
                    const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,
                    const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed,

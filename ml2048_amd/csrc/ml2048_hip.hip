@@ -878,7 +878,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
 // ids after a rollout.  scratch: [0, N*W) exclusive prefix of popcounts inside each step's flag
 // row; [N*W, N*W+N] exclusive prefix of per-step totals (last entry = grand total).
 __global__ __launch_bounds__(256) void k_ids_rowscan(const uint64_t *__restrict__ flags, int64_t W, int N,
-                                                     int32_t *__restrict__ scratch) {
+                                                     int32_t *__restrict__ scratch,
+                                                     const int32_t *__restrict__ game_count, int32_t snap_slot,
+                                                     int32_t *__restrict__ step_resets) {
     __shared__ int wave_tot[4];
     __shared__ int carry_s;
     const int t = blockIdx.x;
@@ -904,7 +906,13 @@ __global__ __launch_bounds__(256) void k_ids_rowscan(const uint64_t *__restrict_
         if (threadIdx.x == 255) carry_s = carry + wave_base + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) scratch[(int64_t)N * W + t] = carry_s; // per-step total (scanned next)
+    if (threadIdx.x == 0) {
+        scratch[(int64_t)N * W + t] = carry_s; // per-step total (scanned by the consumer)
+        if (step_resets) step_resets[t] = carry_s;
+        // the game counter as of before this rollout: k_ids_assign reads it from here while one of
+        // its threads writes the new value
+        if (t == 0) scratch[snap_slot] = *game_count;
+    }
 }
 
 __global__ __launch_bounds__(64) void k_ids_stepscan(int32_t *__restrict__ tot, int N,
@@ -928,13 +936,44 @@ __global__ __launch_bounds__(64) void k_ids_stepscan(int32_t *__restrict__ tot, 
     if (lane == 0) tot[N] = carry;
 }
 
+// SCAN = true: the per-step totals are still unscanned; every workgroup scans them into LDS itself
+// (N ints - cheaper than a separate single-wave kernel and its launch gap).  SCAN = false: scratch
+// already holds the exclusive prefix (k_ids_stepscan; used when N is too large for LDS).
+template <bool SCAN>
 __global__ __launch_bounds__(kBlock) void k_ids_assign(ml2048_state st, int64_t M, int N, int64_t W,
                                                        const uint64_t *__restrict__ flags,
                                                        const int32_t *__restrict__ last_reset,
                                                        const int32_t *__restrict__ scratch,
                                                        int32_t *__restrict__ game_count, int32_t gc_snapshot_slot) {
+    extern __shared__ int32_t step_lds[]; // SCAN: [N + 1] exclusive prefix of the per-step totals
+    __shared__ int32_t chunk_excl[kBlock + 1];
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int32_t *step_base = scratch + (int64_t)N * W;
+    const int32_t *tot = scratch + (int64_t)N * W;
+    const int32_t *step_base = tot;
+    if (SCAN) {
+        const int tid = threadIdx.x;
+        const int per = (N + kBlock - 1) / kBlock;
+        const int lo = tid * per < N ? tid * per : N, hi = lo + per < N ? lo + per : N;
+        int sum = 0;
+        for (int j = lo; j < hi; ++j) sum += tot[j];
+        chunk_excl[tid + 1] = sum;
+        if (tid == 0) chunk_excl[0] = 0;
+        __syncthreads();
+        for (int off = 1; off < kBlock; off <<= 1) { // inclusive Hillis-Steele over the 256 chunk sums
+            const int v = (tid + 1 > off) ? chunk_excl[tid + 1 - off] : 0;
+            __syncthreads();
+            chunk_excl[tid + 1] += v;
+            __syncthreads();
+        }
+        int run = chunk_excl[tid];
+        for (int j = lo; j < hi; ++j) {
+            step_lds[j] = run;
+            run += tot[j];
+        }
+        if (tid == kBlock - 1) step_lds[N] = chunk_excl[kBlock];
+        __syncthreads();
+        step_base = step_lds;
+    }
     const int32_t gc0 = scratch[gc_snapshot_slot];
     if (i == 0) *game_count = gc0 + step_base[N];
     if (i >= M) return;
@@ -988,8 +1027,6 @@ __global__ __launch_bounds__(kBlock) void k_gae(int64_t U, int64_t S, int64_t G,
         if (delta_out) delta_out[k] = d;
     }
 }
-
-__global__ void k_snapshot(const int32_t *__restrict__ src, int32_t *__restrict__ dst) { *dst = *src; }
 
 uint64_t two_threshold(double two_prob) {
     double t = two_prob * 4294967296.0;
@@ -1185,6 +1222,23 @@ int64_t ml2048_rollout_scratch_ints(int64_t M, int32_t N) {
     return (int64_t)N * ml2048_rollout_flag_words(M) + N + 2;
 }
 
+// schedule upload: 16 B per lane straight from device-accessible host memory
+__global__ __launch_bounds__(kBlock) void k_upload(uint4 *__restrict__ dst, const uint4 *__restrict__ src, int64_t n16) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += (int64_t)gridDim.x * kBlock)
+        dst[i] = src[i];
+}
+
+int ml2048_upload(void *stream, void *dst, const void *src_host, int64_t nbytes) {
+    if (!dst || !src_host || nbytes <= 0) return fail(ML2048_E_INVALID, "dst/src_host/nbytes");
+    if (((uintptr_t)dst | (uintptr_t)src_host) % 16) return fail(ML2048_E_ALIGN, "dst and src_host must be 16-byte aligned");
+    const int64_t n16 = (nbytes + 15) / 16;
+    int64_t blocks = cdiv(n16, kBlock);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_upload, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, (uint4 *)dst,
+                       (const uint4 *)src_host, n16);
+    return check_launch("ml2048_upload");
+}
+
 static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
                           const uint8_t *perm_epochs, const uint32_t *two_masks, const int32_t *schedule, int32_t n_epochs,
                           int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0, uint8_t *actions_out,
@@ -1285,11 +1339,17 @@ int ml2048_rollout_finish_ids(void *stream, int64_t M, const ml2048_state *st, i
     const int64_t W = ml2048_rollout_flag_words(M);
     const int64_t snap = (int64_t)N * W + N + 1;
     if (snap > 0x7FFFFFFF) return fail(ML2048_E_UNSUPPORTED, "N*M too large for one finish_ids call");
-    hipLaunchKernelGGL(k_snapshot, dim3(1), dim3(1), 0, s, game_count, scratch + snap);
-    hipLaunchKernelGGL(k_ids_rowscan, dim3((unsigned)N), dim3(256), 0, s, reset_flags, W, N, scratch);
-    hipLaunchKernelGGL(k_ids_stepscan, dim3(1), dim3(64), 0, s, scratch + (int64_t)N * W, N, step_resets);
-    hipLaunchKernelGGL(k_ids_assign, dim3((unsigned)cdiv(M, kBlock)), dim3(kBlock), 0, s, *st, M, N, W, reset_flags,
-                       last_reset, scratch, game_count, (int32_t)snap);
+    hipLaunchKernelGGL(k_ids_rowscan, dim3((unsigned)N), dim3(256), 0, s, reset_flags, W, N, scratch, game_count,
+                       (int32_t)snap, step_resets);
+    const dim3 grid((unsigned)cdiv(M, kBlock)), block(kBlock);
+    if (N <= 8192) { // two launches: every workgroup of the assignment scans the N step totals itself
+        hipLaunchKernelGGL((k_ids_assign<true>), grid, block, (size_t)(N + 1) * sizeof(int32_t), s, *st, M, N, W,
+                           reset_flags, last_reset, scratch, game_count, (int32_t)snap);
+    } else {
+        hipLaunchKernelGGL(k_ids_stepscan, dim3(1), dim3(64), 0, s, scratch + (int64_t)N * W, N, (int32_t *)nullptr);
+        hipLaunchKernelGGL((k_ids_assign<false>), grid, block, 0, s, *st, M, N, W, reset_flags, last_reset, scratch,
+                           game_count, (int32_t)snap);
+    }
     return check_launch("ml2048_rollout_finish_ids");
 }
 

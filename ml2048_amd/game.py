@@ -328,10 +328,14 @@ class VecGame:
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=dev)
         cur = torch.cuda.current_stream(dev)
-        with torch.cuda.stream(self._copy_stream):
-            self._copy_stream.wait_event(slot[3])  # the rollout that last read the device buffer
-            slot[1][:nbytes].copy_(slot[0][:nbytes], non_blocking=True)
-            slot[2].record(self._copy_stream)
+        side = self._copy_stream
+        side.wait_event(slot[3])  # the rollout that last read the device buffer
+        # a copy kernel reading the pinned buffer directly (csrc k_upload), not hipMemcpyAsync: the
+        # runtime's async-copy path stalled the host for ~7 ms a few times per run (measured)
+        with self._dev_ctx():
+            _lib.check(self._L.ml2048_upload(side.cuda_stream, slot[1].data_ptr(), slot[0].data_ptr(), nbytes),
+                       "upload")
+        slot[2].record(side)
         cur.wait_event(slot[2])
         return slot[1]
 

@@ -341,7 +341,8 @@ def test_rollout_c4_total_size_on_one_gpu_vs_oracle(amd, oracle):
 
 
 @pytest.mark.parametrize("M,N,masked,reward", [(1000, 300, True, "improved"), (65, 64, False, "rank"),
-                                               (4096, 256, True, "maxcell")])
+                                               (4096, 256, True, "maxcell"),
+                                               (130, 8300, False, "normal")])  # N > 8192: the 3-kernel id scan
 def test_rollout_small_cases(amd, oracle, M, N, masked, reward):
     _check_rollout(amd, oracle, M, N, 12345, reward, masked)
 
