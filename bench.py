@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary stepwise measurement")
+    ap.add_argument("--ids", choices=["deferred", "inline"], default="deferred",
+                    help="fused mode: where the ordered game-id scan of a rollout runs - 'deferred' = on a side "
+                         "stream beside the next rollout's kernel, 'inline' = on the launch stream")
     ap.add_argument("--event-every", type=int, default=8,
                     help="bracket every k-th timed launch of the dominant kernel with HIP events (the pair of "
                          "timestamp packets costs a few us of GPU idle per launch, so not every launch carries one)")
@@ -208,7 +211,8 @@ def main():
         if args.mode in ("fused", "fused-traj"):
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if timed else None
             env.rollout(N, masked=bool(args.masked), act_seed=7 + rank, act_counter=counter[0], kernel_events=ev,
-                        prefetch_next=bool(args.prefetch), trajectory=traj)
+                        prefetch_next=bool(args.prefetch), trajectory=traj,
+                        finish_ids="deferred" if args.ids == "deferred" else True)
             counter[0] += N
             if ev:
                 kern_ms.append(ev)
@@ -341,7 +345,7 @@ def main():
                                    f"({'masked' if args.masked else 'unmasked'} uniform actions sampled on device, "
                                    f"table spawn = bit-exact mode), mode={args.mode}",
                        "boards_per_gpu": M, "env_steps_per_step": N, "mode": args.mode, "sharding": f"replicas x{world}",
-                       "host_schedule": args.schedule, "spawn": "table (bit-exact with the reference's PCG64 tables)"},
+                       "host_schedule": args.schedule, "id_scan": args.ids, "spawn": "table (bit-exact with the reference's PCG64 tables)"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         line.update(extras)

@@ -257,6 +257,20 @@ int64_t ml2048_rollout_flag_words(int64_t M);
 int64_t ml2048_rollout_scratch_ints(int64_t M, int32_t N);
 
 /*
+ * ml2048_rollout that ALSO uploads the next rollout's packed schedule: the same launch copies
+ * next_nbytes (rounded up to 16) from next_src_host (pinned / registered host memory, 16-byte
+ * aligned) to next_dst (device, 16-byte aligned, a buffer this launch does not read).  Stream order
+ * alone then guarantees the data is there for the next launch: a chain of fused rollouts needs no
+ * copy stream and no event (the reference keeps its tables in host memory, game_numba.py:589-591,
+ * so it has no counterpart to this copy).
+ */
+int ml2048_rollout_chain(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
+                         const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,
+                         const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed,
+                         uint64_t act_counter0, uint64_t *reset_flags, int32_t *last_reset,
+                         const void *next_src_host, void *next_dst, int64_t next_nbytes);
+
+/*
  * Upload of a pre-drawn schedule: a copy KERNEL that reads device-accessible (pinned / registered)
  * host memory directly, so that the upload is an ordinary launch on `stream` (typically a side
  * stream, overlapped with the previous rollout) and involves neither the copy engine nor a host

@@ -28,30 +28,45 @@ def is_stale() -> bool:
     return any(os.path.exists(p) and os.path.getmtime(p) > t for p in SOURCES + HOST_SOURCES + HEADERS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not is_stale():
-        return LIB_PATH
+def build(force: bool = False, verbose: bool = False, extra_hipcc_flags=(), out: str | None = None) -> str:
+    """Compile and link the library.  `extra_hipcc_flags` / `out` build an A/B variant next to the
+    default one (`ML2048_HIP_LIB=<out>` selects it at load time); they never change the default build."""
+    if out is None and not extra_hipcc_flags:
+        if not force and not is_stale():
+            return LIB_PATH
+    lib_path = out or LIB_PATH
+    suffix = ".ab.o" if out else ".o"
     objs = []
     for src in HOST_SOURCES:
-        obj = os.path.splitext(src)[0] + ".o"
+        obj = os.path.splitext(src)[0] + suffix
         cmd = [os.environ.get("CXX", "g++"), "-O2", "-mssse3", "-std=c++17", "-fPIC", "-fopenmp", "-pthread", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         objs.append(obj)
     for src in SOURCES:
-        obj = os.path.splitext(src)[0] + ".o"
-        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+        obj = os.path.splitext(src)[0] + suffix
+        # ML2048_SCHED=max-ilp (A/B only): -1.8 % on the default rollout kernel at C2 (178.7 -> 175.5 us, fewer
+        # s_nop between v_cmp and v_cndmask) but +9..20 % on the trajectory-writing instantiations (more
+        # VGPRs, loads and stores interleaved), and it is a per-file flag - so the compiler's own schedule stays
+        sched = os.environ.get("ML2048_SCHED", "default")
+        sched_flags = [] if sched == "default" else ["-mllvm", f"-amdgpu-sched-strategy={sched}"]
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *sched_flags, *extra_hipcc_flags,
+               "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH, *objs, "-lgomp", "-lpthread"]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", lib_path, *objs, "-lgomp", "-lpthread"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    # python -m ml2048_amd.build [--force] [--out variant.so -- <extra hipcc flags>]
+    argv = sys.argv[1:]
+    extra = argv[argv.index("--") + 1:] if "--" in argv else []
+    out_path = argv[argv.index("--out") + 1] if "--out" in argv else None
+    print(build(force="--force" in argv, verbose=True, extra_hipcc_flags=extra, out=out_path))

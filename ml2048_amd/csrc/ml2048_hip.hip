@@ -684,7 +684,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                                                     uint64_t *__restrict__ digests_out,
                                                     uint64_t *__restrict__ reset_flags, int64_t flag_words,
                                                     int32_t *__restrict__ last_reset, uint64_t spawn_seed,
-                                                    uint64_t spawn_counter0, uint64_t thr, ml2048_traj traj) {
+                                                    uint64_t spawn_counter0, uint64_t thr, ml2048_traj traj,
+                                                    const uint4 *__restrict__ up_src, uint4 *__restrict__ up_dst,
+                                                    int64_t up_n16, unsigned up_blocks) {
     // re-deal flags of up to kFlagChunk steps are parked in LDS so that the step loop holds no global
     // store (its acknowledgement would share the vmcnt queue with the prefetched loads)
     __shared__ unsigned long long flag_park[kBlock / 64][kFlagChunk];
@@ -696,6 +698,17 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
     const int64_t ii = live ? i : M - 1; // tail lanes shadow the last board (loads only, no stores)
     const int lane = threadIdx.x & 63;
     const int64_t wave_global = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    // Chained upload: this launch also copies the NEXT rollout's packed schedule from device-accessible
+    // host memory into the other device buffer - ordered before the next launch by the stream itself,
+    // so the upload needs neither a copy stream nor an event (a cross-stream wait in front of every
+    // rollout kernel cost ~19 us of idle GPU, tools/debug/marker_cost.py).  The copy is done by extra
+    // workgroups appended to the grid (up_blocks of them): they share CUs with the board workgroups and
+    // are gone after a few microseconds, so no board ever waits for a PCIe read.
+    if (up_blocks > 0 && blockIdx.x >= gridDim.x - up_blocks) {
+        const int64_t first = (int64_t)(blockIdx.x - (gridDim.x - up_blocks)) * kBlock + threadIdx.x;
+        for (int64_t j = first; j < up_n16; j += (int64_t)up_blocks * kBlock) up_dst[j] = up_src[j];
+        return;
+    }
 
     StepRegs s;
     s.board = load_board(st.board, ii);
@@ -734,40 +747,55 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
     // ahead.  The re-deal only reads the first two cells of its row, so that load is a single dword
     // (a dwordx4 with three dead result registers makes the compiler wait for the load mid-step before
     // it can reuse them).  Indices are clamped instead of branched around at the end of the schedule.
+    // With the optional outputs (EXTRAS) the loop also issues stores, which share the in-order vmcnt
+    // queue with the loads: a row fetched a step ahead would make the wait at the top of the next
+    // step cover this step's stores as well (fused-traj at 1 M boards: 1.89 -> 2.42 ms).  There the rows
+    // are fetched in the step that uses them and only the scalar schedule entry runs ahead.
+    constexpr int VPF = EXTRAS ? 0 : 1;   // how many steps ahead the vector loads run
     int e1 = 0;
-    int64_t rp1 = 0, rs1 = 0;           // schedule entry of step t+1
-    uint32_t n_two_mask = 0, n_perm_p = 0; // data of step t, in flight since the previous iteration
+    int64_t rp1 = 0, rs1 = 0;             // schedule entry of step t + VPF
+    uint32_t n_two_mask = 0, n_perm_p = 0; // VPF: data of step t, in flight since the previous iteration
     uint32_t n_perm_s[4] = {0, 0, 0, 0};
     // an epoch index is clamped to the tables that exist: a corrupted schedule then yields wrong
     // boards, never an out-of-bounds read (rows are already taken modulo the table size)
     const uint32_t e_last = (uint32_t)(n_epochs - 1);
     if (!FAST) {
         const uint32_t e0r = (uint32_t)schedule[0];
-        const int e0 = (int)(e0r < e_last ? e0r : e_last);
-        const uint8_t *tab0 = perm_epochs + (int64_t)e0 * (ML2048_RAND_SIZE * 16);
-        n_two_mask = two_masks[e0];
-        n_perm_p = load_perm_head(tab0, (int64_t)schedule[1] + idx_base + ii);
-        load_perm_row(tab0, (int64_t)schedule[2] + idx_base + ii, n_perm_s);
-        const int j1 = N > 1 ? 1 : 0;
-        const uint32_t e1r = (uint32_t)schedule[3 * j1 + 0];
-        e1 = (int)(e1r < e_last ? e1r : e_last);
-        rp1 = schedule[3 * j1 + 1];
-        rs1 = schedule[3 * j1 + 2];
+        e1 = (int)(e0r < e_last ? e0r : e_last);
+        rp1 = schedule[1];
+        rs1 = schedule[2];
+        if (VPF) {
+            const uint8_t *tab0 = perm_epochs + (int64_t)e1 * (ML2048_RAND_SIZE * 16);
+            n_two_mask = two_masks[e1];
+            n_perm_p = load_perm_head(tab0, rp1 + idx_base + ii);
+            load_perm_row(tab0, rs1 + idx_base + ii, n_perm_s);
+            const int j1 = N > 1 ? 1 : 0;
+            const uint32_t e1r = (uint32_t)schedule[3 * j1 + 0];
+            e1 = (int)(e1r < e_last ? e1r : e_last);
+            rp1 = schedule[3 * j1 + 1];
+            rs1 = schedule[3 * j1 + 2];
+        }
     }
     for (int t0 = 0; t0 < N; t0 += kFlagChunk) {
         const int t1 = t0 + kFlagChunk < N ? t0 + kFlagChunk : N;
         for (int t = t0; t < t1; ++t) {
             // table mode: the pre-drawn host schedule; fast mode: rocRAND Philox words keyed
             // (spawn_seed; board; 2*(counter0+t) for the deal, +1 for the step) as the per-step API does
-            const uint32_t two_mask = n_two_mask;
-            const uint32_t perm_p = n_perm_p;
-            const uint32_t perm_s[4] = {n_perm_s[0], n_perm_s[1], n_perm_s[2], n_perm_s[3]};
+            uint32_t two_mask = n_two_mask;
+            uint32_t perm_p = n_perm_p;
+            uint32_t perm_s[4] = {n_perm_s[0], n_perm_s[1], n_perm_s[2], n_perm_s[3]};
             if (!FAST) {
                 const uint8_t *tab1 = perm_epochs + (int64_t)e1 * (ML2048_RAND_SIZE * 16);
-                n_two_mask = two_masks[e1];
-                n_perm_p = load_perm_head(tab1, rp1 + idx_base + ii);
-                load_perm_row(tab1, rs1 + idx_base + ii, n_perm_s);
-                const int j2 = t + 2 < N ? t + 2 : N - 1;
+                if (VPF) { // requests for step t+1, consumed one iteration later
+                    n_two_mask = two_masks[e1];
+                    n_perm_p = load_perm_head(tab1, rp1 + idx_base + ii);
+                    load_perm_row(tab1, rs1 + idx_base + ii, n_perm_s);
+                } else {
+                    two_mask = two_masks[e1];
+                    perm_p = load_perm_head(tab1, rp1 + idx_base + ii);
+                    load_perm_row(tab1, rs1 + idx_base + ii, perm_s);
+                }
+                const int j2 = t + 1 + VPF < N ? t + 1 + VPF : N - 1;
                 const uint32_t e2r = (uint32_t)schedule[3 * j2 + 0];
                 e1 = (int)(e2r < e_last ? e2r : e_last);
                 rp1 = schedule[3 * j2 + 1];
@@ -1243,8 +1271,15 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
                           const uint8_t *perm_epochs, const uint32_t *two_masks, const int32_t *schedule, int32_t n_epochs,
                           int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0, uint8_t *actions_out,
                           uint64_t *digests_out, uint64_t *reset_flags, int32_t *last_reset, uint64_t spawn_seed,
-                          uint64_t spawn_counter0, double two_prob, const ml2048_traj *traj_or_null) {
+                          uint64_t spawn_counter0, double two_prob, const ml2048_traj *traj_or_null,
+                          const void *up_src = nullptr, void *up_dst = nullptr, int64_t up_nbytes = 0) {
     ml2048_traj traj = {};
+    if (up_src || up_dst || up_nbytes) {
+        if (!up_src || !up_dst || up_nbytes <= 0) return fail(ML2048_E_INVALID, "next_src_host/next_dst/next_nbytes");
+        if (((uintptr_t)up_src | (uintptr_t)up_dst) % 16) return fail(ML2048_E_ALIGN, "next_src_host and next_dst must be 16-byte aligned");
+    }
+    const int64_t up_n16 = (up_nbytes + 15) / 16;
+    const unsigned up_blocks = up_n16 > 0 ? (unsigned)(cdiv(up_n16, kBlock) < 64 ? cdiv(up_n16, kBlock) : 64) : 0u;
     if (traj_or_null) {
         traj = *traj_or_null;
         if (((uintptr_t)traj.state | (uintptr_t)traj.next_state) % 16)
@@ -1253,7 +1288,7 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
              (uintptr_t)traj.step | (uintptr_t)traj.action_log_prob) % 4)
             return fail(ML2048_E_ALIGN, "4-byte trajectory outputs must be 4-byte aligned");
     }
-    const dim3 grid((unsigned)cdiv(M, kBlock)), block(kBlock);
+    const dim3 grid((unsigned)cdiv(M, kBlock) + up_blocks), block(kBlock); // board workgroups, then the upload's
     const int64_t W = ml2048_rollout_flag_words(M);
     const uint64_t thr = two_threshold(two_prob);
     const bool extras = actions_out || digests_out || traj_or_null;
@@ -1261,7 +1296,7 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
     hipLaunchKernelGGL((k_rollout<K, F, X>), grid, block, 0, s, *st, M, idx_base, N, perm_epochs, two_masks, \
                        schedule, n_epochs, masked, act_seed, act_counter0, actions_out, digests_out,         \
                        reset_flags, W,                                                                       \
-                       last_reset, spawn_seed, spawn_counter0, thr, traj)
+                       last_reset, spawn_seed, spawn_counter0, thr, traj, (const uint4 *)up_src, (uint4 *)up_dst, up_n16, up_blocks)
 #define ML_LAUNCH(K, F)          \
     if (extras) {                \
         ML_LAUNCH2(K, F, true);  \
@@ -1300,6 +1335,22 @@ int ml2048_rollout(void *stream, int64_t M, int64_t idx_base, const ml2048_state
     return launch_rollout((hipStream_t)stream, false, M, idx_base, st, N, perm_epochs, two_masks, schedule, n_epochs, reward_kind,
                           masked, act_seed, act_counter0, actions_out, digests_out, reset_flags, last_reset, 0, 0, 0.0,
                           nullptr);
+}
+
+int ml2048_rollout_chain(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
+                         const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,
+                         const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0,
+                         uint64_t *reset_flags, int32_t *last_reset, const void *next_src_host, void *next_dst,
+                         int64_t next_nbytes) {
+    if (int rc = check_state(M, st)) return rc;
+    if (N <= 0 || n_epochs <= 0) return fail(ML2048_E_INVALID, "N=%d n_epochs=%d must be positive", N, n_epochs);
+    if (!perm_epochs || !two_masks || !schedule || !reset_flags || !last_reset)
+        return fail(ML2048_E_INVALID, "perm_epochs/two_masks/schedule/reset_flags/last_reset is NULL");
+    if ((uintptr_t)perm_epochs % 16) return fail(ML2048_E_ALIGN, "perm_epochs must be 16-byte aligned");
+    if (idx_base < 0) return fail(ML2048_E_INVALID, "idx_base must be >= 0");
+    return launch_rollout((hipStream_t)stream, false, M, idx_base, st, N, perm_epochs, two_masks, schedule, n_epochs, reward_kind,
+                          masked, act_seed, act_counter0, nullptr, nullptr, reset_flags, last_reset, 0, 0, 0.0, nullptr,
+                          next_src_host, next_dst, next_nbytes);
 }
 
 int ml2048_rollout_traj(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,

@@ -187,9 +187,16 @@ class VecGame:
         self._schedule_mode = schedule
         self._sstream = None        # ml2048_sched_stream handle
         self._sstream_n = 0
-        self._stage = [None, None, None]  # schedule upload ring: [pinned, device, copied_ev, consumed_ev]
-        self._stage_i = 0
-        self._copy_stream = None
+        self._ids_stream = None     # rollout(finish_ids="deferred"): side stream of the id scan ...
+        self._ids_done = None       # ... its completion event, and whether the launch stream still has to
+        self._ids_pending = False   # wait for it before anything touches ids / the game counter
+        self._spin = [None, None, None, None]  # pinned staging ring: [tensor, event of the launch that reads it]
+        self._spin_i = 0
+        self._roll_ev = None        # ring of per-rollout events (ONE record per rollout, after its kernel)
+        self._roll_i = 0
+        self._sdev = [None, None]   # device-side packed schedules (the resident one and the next one)
+        self._sdev_i = 0
+        self._la = None             # host-async: the NEXT schedule, already taken from the stream and uploaded
         self._sstream_after = None  # generator / counter / tables after the last CONSUMED schedule
         self._rng_on_device = False  # True while the device copy of the generator is the current one
         if step_mapping not in ("lane", "wave"):
@@ -209,13 +216,13 @@ class VecGame:
         self.reward = torch.empty((M,), dtype=f32, device=dev)
         self.terminated = torch.empty((M,), dtype=u8, device=dev)
         self.invalid = torch.empty((M,), dtype=u8, device=dev)
-        self.game_id = torch.empty((M,), dtype=i32, device=dev)
+        self._game_id = torch.empty((M,), dtype=i32, device=dev)  # public as the `game_id` property
         self.prev_state = torch.empty((M, 16), dtype=u8, device=dev)
         self.prev_valid_actions = torch.empty((M, 4), dtype=u8, device=dev)
         self._state = _lib.State(
             self.board.data_ptr(), self.merged.data_ptr(), self.valid_actions.data_ptr(),
             self.step_count.data_ptr(), self.score.data_ptr(), self.reward.data_ptr(),
-            self.terminated.data_ptr(), self.invalid.data_ptr(), self.game_id.data_ptr(),
+            self.terminated.data_ptr(), self.invalid.data_ptr(), self._game_id.data_ptr(),
             self.prev_state.data_ptr(), self.prev_valid_actions.data_ptr(),
         )
         self._randperm_dev = torch.empty((RAND_SIZE, 16), dtype=u8, device=dev)
@@ -233,8 +240,25 @@ class VecGame:
         self.reset()  # :584 (unseeded, as the reference constructor does)
 
     # ------------------------------------------------------------------------------------------
-    def _stream(self) -> int:
-        """hipStream_t of torch's current stream on this device (raw accessor: ~0.3 us vs ~4 us)."""
+    def join_ids(self) -> None:
+        """Order the launch stream after a deferred id scan (`rollout(finish_ids="deferred")`).  Every
+        method of this class does it implicitly; call it before reading a deferred rollout's
+        `step_resets` with your own torch code."""
+        if self._ids_pending:
+            torch.cuda.current_stream(self.device).wait_event(self._ids_done)
+            self._ids_pending = False
+
+    @property
+    def game_id(self) -> torch.Tensor:
+        """(M,) int32 device tensor of game ids (the record's `id`, game_numba.py:641-644)."""
+        self.join_ids()
+        return self._game_id
+
+    def _stream(self, join: bool = True) -> int:
+        """hipStream_t of torch's current stream on this device (raw accessor: ~0.3 us vs ~4 us).
+        join=False only for launches that touch neither ids nor the game counter (the rollout kernel)."""
+        if join and self._ids_pending:
+            self.join_ids()
         try:
             return torch._C._cuda_getCurrentRawStream(self.device.index)
         except AttributeError:  # pragma: no cover - older/newer torch without the raw accessor
@@ -285,6 +309,7 @@ class VecGame:
             return
         self._L.ml2048_sched_stream_destroy(self._sstream)
         self._sstream = None
+        self._la = None  # a schedule taken ahead of its rollout is simply dropped with the stream
         after = self._sstream_after
         self._sstream_after = None
         if after is not None:
@@ -300,44 +325,35 @@ class VecGame:
             self._rng.randfloat[...] = flt
             self._tables_dirty = True
 
-    def _stage_slot(self, nbytes: int):
-        """Next slot of the schedule upload ring, its pinned buffer safe to overwrite."""
-        i = self._stage_i
-        self._stage_i = (i + 1) % len(self._stage)
-        slot = self._stage[i]
+    def _pack_pinned(self, sched, epochs, masks, N: int):
+        """Pack [epoch tables | schedule | masks] (16-byte aligned sections) into the next pinned buffer of
+        the ring.  Returns (slot, layout): slot = [pinned tensor, event]; layout = (E, o_sched, o_mask, nbytes)."""
+        E = int(epochs.shape[0])
+        o_sched = E * RAND_SIZE * 16
+        o_mask = o_sched + ((N * 12 + 15) // 16) * 16
+        nbytes = ((o_mask + E * 4 + 15) // 16) * 16
+        i = self._spin_i
+        self._spin_i = (i + 1) % len(self._spin)
+        slot = self._spin[i]
+        if slot is not None and slot[1] is not None:
+            slot[1].synchronize()  # the launch that read this buffer (a ring length ago) has finished
         if slot is None or slot[0].numel() < nbytes:
-            if slot is not None:
-                torch.cuda.synchronize(self.device)  # rare (a schedule with unusually many epochs)
-            cap = max(2 * nbytes, 1 << 19)
-            slot = [torch.empty((cap,), dtype=torch.uint8, pin_memory=True),
-                    torch.empty((cap,), dtype=torch.uint8, device=self.device),
-                    torch.cuda.Event(), torch.cuda.Event()]
-            self._stage[i] = slot
-            # The caching allocator hands out blocks whose previous uses are ordered on the CURRENT
-            # stream only; the copy stream writes this one, so it must first catch up with everything
-            # queued there (a block freed by another env may still be awaiting a queued kernel).
-            if self._copy_stream is None:
-                self._copy_stream = torch.cuda.Stream(device=self.device)
-            self._copy_stream.wait_stream(torch.cuda.current_stream(self.device))
-        else:
-            slot[2].synchronize()  # the copy that last read the pinned buffer (3 rollouts ago)
-        return slot
+            slot = [torch.empty((max(2 * nbytes, 1 << 19),), dtype=torch.uint8, pin_memory=True), None]
+            self._spin[i] = slot
+        packed = slot[0].numpy()
+        packed[:o_sched] = epochs.reshape(-1)
+        packed[o_sched:o_sched + N * 12] = sched.view(np.uint8).reshape(-1)
+        packed[o_mask:o_mask + E * 4] = masks.view(np.uint8)
+        return slot, (E, o_sched, o_mask, nbytes)
 
-    def _stage_upload(self, slot, nbytes: int):
-        dev = self.device
-        if self._copy_stream is None:
-            self._copy_stream = torch.cuda.Stream(device=dev)
-        cur = torch.cuda.current_stream(dev)
-        side = self._copy_stream
-        side.wait_event(slot[3])  # the rollout that last read the device buffer
-        # a copy kernel reading the pinned buffer directly (csrc k_upload), not hipMemcpyAsync: the
-        # runtime's async-copy path stalled the host for ~7 ms a few times per run (measured)
-        with self._dev_ctx():
-            _lib.check(self._L.ml2048_upload(side.cuda_stream, slot[1].data_ptr(), slot[0].data_ptr(), nbytes),
-                       "upload")
-        slot[2].record(side)
-        cur.wait_event(slot[2])
-        return slot[1]
+    def _dev_sched_buf(self, idx: int, nbytes: int) -> torch.Tensor:
+        buf = self._sdev[idx]
+        if buf is None or buf.numel() < nbytes:
+            # only ever touched by launches on the current stream, so the caching allocator's
+            # stream-ordered reuse of the old block is safe
+            buf = torch.empty((max(2 * nbytes, 1 << 19),), dtype=torch.uint8, device=self.device)
+            self._sdev[idx] = buf
+        return buf
 
     def _next_schedule_async(self, N: int):
         L = self._L
@@ -369,9 +385,10 @@ class VecGame:
         sched = view(p_s, N * 12, np.int32).reshape(N, 3)
         epochs = view(p_e, E * RAND_SIZE * 16, np.uint8).reshape(E, RAND_SIZE, 16)
         masks = view(p_m, E * 4, np.uint32)
-        self._sstream_after = (after, rs.value, view(p_rp, RAND_SIZE * 16, np.uint8).reshape(RAND_SIZE, 16).copy(),
-                               view(p_rf, RAND_SIZE * 4, np.float32).copy())
-        return sched, epochs, masks  # views into the slot: valid until _release_schedule_async()
+        after_state = (after, rs.value, view(p_rp, RAND_SIZE * 16, np.uint8).reshape(RAND_SIZE, 16).copy(),
+                       view(p_rf, RAND_SIZE * 4, np.float32).copy())
+        # views into the stream's slot (valid until ml2048_sched_stream_release) + generator/tables after it
+        return sched, epochs, masks, after_state
 
     def _pull_rng(self) -> None:
         """Make the host generator current again (before any host-side draw or inspection)."""
@@ -418,6 +435,7 @@ class VecGame:
 
     @property
     def _game_count(self) -> int:
+        self.join_ids()
         return int(self._game_count_dev.item())
 
     @property
@@ -673,7 +691,7 @@ class VecGame:
         return slot["perm"], slot["sched"], slot["mask"], cap
 
     def rollout(self, n_steps: int, *, masked: bool = True, act_seed: int = 0, act_counter: int = 0,
-                record_actions: bool = False, digests: bool = False, finish_ids: bool = True,
+                record_actions: bool = False, digests: bool = False, finish_ids=True,
                 kernel_events: Optional[tuple] = None, prefetch_next: bool = False,
                 trajectory: Optional[dict] = None):
         """N x {prepare; uniform-random actions; step} fused into one kernel launch, bit-exact
@@ -684,6 +702,10 @@ class VecGame:
         uint64) | None, step_resets (N,) int32 | None.
         kernel_events: optional (start, end) torch.cuda.Event pair recorded on the launch stream
         immediately around the rollout kernel (bench.py times the dominant kernel with it).
+        finish_ids: True = number the re-dealt games (ordered ids, game counter, step_resets) on the launch
+        stream right after the kernel; "deferred" = the same scan on a side stream, overlapped with whatever
+        the launch stream does next (every method of this class waits for it before it touches ids; read
+        `step_resets` from your own torch code only after join_ids()); False = skip it.
         prefetch_next: draw the host schedule of the next rollout(n_steps) on a worker thread while
         this one runs on the GPU (results are identical either way).
         trajectory: dict of [N, M, ...] device tensors keyed like REPLAY_SPEC (train_ops.new_buffers((N, M),
@@ -698,30 +720,48 @@ class VecGame:
         if on_device:
             perm_dev, sched_dev, mask_dev, E = self._device_schedule(N)
         elif not fast:
-            # the host schedule (independent of game state): one native call, or already drawn ahead
-            if self._schedule_mode == "host-async":
-                sched, epochs, masks = self._next_schedule_async(N)
-            else:
-                sched, epochs, masks = self._next_schedule(N)
-            if prefetch_next:
-                # start drawing the NEXT schedule right away: it then overlaps this call's packing,
-                # upload and launches as well as the GPU work
-                self._start_prefetch(N)
-            # one packed H2D copy: [epoch tables | schedule | masks], each section 16-byte aligned,
-            # from pinned memory on a side stream so that neither the host nor the copy waits for the
-            # previous rollout's kernels (a pageable copy on the launch stream did both: ~55 us of idle
-            # GPU per rollout at C2)
-            E = epochs.shape[0]
-            o_sched = E * RAND_SIZE * 16
-            o_mask = o_sched + ((N * 12 + 15) // 16) * 16
-            slot = self._stage_slot(o_mask + E * 4)
-            packed = slot[0].numpy()
-            packed[:o_sched] = epochs.reshape(-1)
-            packed[o_sched:o_sched + N * 12] = sched.view(np.uint8).reshape(-1)
-            packed[o_mask:o_mask + E * 4] = masks.view(np.uint8)
-            if self._schedule_mode == "host-async":
-                _lib.check(L.ml2048_sched_stream_release(self._sstream), "sched_stream_release")
-            packed_dev = self._stage_upload(slot, o_mask + E * 4)
+            # The host schedule does not depend on game state: it is packed as [epoch tables | schedule |
+            # masks] in pinned memory and brought to the device by a kernel on THIS stream - either a
+            # small copy kernel in front of the rollout, or (host-async, plain rollouts) by the previous
+            # rollout's own launch (ml2048_rollout_chain), which leaves nothing between two rollout kernels.
+            asyn = self._schedule_mode == "host-async"
+            if asyn and self._la is not None and self._la["N"] != N:
+                self._close_sched_stream()  # the schedule taken ahead was for another length: drop it
+            cur = self._la if asyn else None
+            self._la = None
+            staged = []  # pinned slots read by this rollout's launches: released by its event
+            with self._dev_ctx():
+                if cur is None:
+                    if asyn:
+                        sched, epochs, masks, after_state = self._next_schedule_async(N)
+                    else:
+                        sched, epochs, masks = self._next_schedule(N)
+                        after_state = None
+                        if prefetch_next:
+                            self._start_prefetch(N)  # the NEXT schedule, on a worker thread (sync mode)
+                    pslot, (E, o_sched, o_mask, nbytes) = self._pack_pinned(sched, epochs, masks, N)
+                    if asyn:
+                        _lib.check(L.ml2048_sched_stream_release(self._sstream), "sched_stream_release")
+                    self._sdev_i ^= 1
+                    dbuf = self._dev_sched_buf(self._sdev_i, nbytes)
+                    _lib.check(L.ml2048_upload(self._stream(join=False), dbuf.data_ptr(), pslot[0].data_ptr(), nbytes), "upload")
+                    staged.append(pslot)
+                    cur = {"N": N, "idx": self._sdev_i, "E": E, "o_sched": o_sched, "o_mask": o_mask, "after": after_state}
+                E, o_sched, o_mask = cur["E"], cur["o_sched"], cur["o_mask"]
+                packed_dev = self._sdev[cur["idx"]]
+                chain = None
+                if asyn and trajectory is None and not record_actions and not digests:
+                    # take the next schedule now and let this launch upload it
+                    sched, epochs, masks, after_next = self._next_schedule_async(N)
+                    nslot, (E2, o_sched2, o_mask2, nbytes2) = self._pack_pinned(sched, epochs, masks, N)
+                    _lib.check(L.ml2048_sched_stream_release(self._sstream), "sched_stream_release")
+                    ndev = self._dev_sched_buf(cur["idx"] ^ 1, nbytes2)
+                    chain = (nslot, ndev, nbytes2)
+                    staged.append(nslot)
+                    self._la = {"N": N, "idx": cur["idx"] ^ 1, "E": E2, "o_sched": o_sched2, "o_mask": o_mask2,
+                                "after": after_next}
+            if asyn:
+                self._sstream_after = cur["after"]  # what _close_sched_stream re-synchronises the generator to
             perm_dev = packed_dev[:o_sched]
             sched_dev = packed_dev[o_sched:o_sched + N * 12]
             mask_dev = packed_dev[o_mask:o_mask + E * 4]
@@ -753,18 +793,24 @@ class VecGame:
                         tuple(buf.shape[:2]) == (N, M), (name, buf.dtype, tuple(buf.shape))
                     setattr(tr, name, buf.data_ptr())
                 _lib.check(L.ml2048_rollout_traj(
-                    self._stream(), M, self._idx_base, self._st(), N, perm_dev.data_ptr(), mask_dev.data_ptr(),
+                    self._stream(join=False), M, self._idx_base, self._st(), N, perm_dev.data_ptr(), mask_dev.data_ptr(),
                     E, sched_dev.data_ptr(), self._reward_kind, int(masked), int(act_seed), int(act_counter),
                     flags.data_ptr(), last.data_ptr(), C.byref(tr)), "rollout_traj")
             elif fast:  # rocRAND spawn: no host schedule at all
                 _lib.check(L.ml2048_rollout_fast(
-                    self._stream(), M, self._idx_base, self._st(), N, self._two_prob, self._spawn_seed,
+                    self._stream(join=False), M, self._idx_base, self._st(), N, self._two_prob, self._spawn_seed,
                     self._fast_counter, self._reward_kind, int(masked), int(act_seed), int(act_counter),
                     a_ptr, d_ptr, flags.data_ptr(), last.data_ptr()), "rollout_fast")
                 self._fast_counter += N
+            elif not on_device and chain is not None:
+                _lib.check(L.ml2048_rollout_chain(
+                    self._stream(join=False), M, self._idx_base, self._st(), N, perm_dev.data_ptr(), mask_dev.data_ptr(),
+                    E, sched_dev.data_ptr(), self._reward_kind, int(masked), int(act_seed), int(act_counter),
+                    flags.data_ptr(), last.data_ptr(), chain[0][0].data_ptr(), chain[1].data_ptr(), chain[2]),
+                    "rollout_chain")
             else:
                 _lib.check(L.ml2048_rollout(
-                    self._stream(), M, self._idx_base, self._st(), N, perm_dev.data_ptr(), mask_dev.data_ptr(),
+                    self._stream(join=False), M, self._idx_base, self._st(), N, perm_dev.data_ptr(), mask_dev.data_ptr(),
                     E, sched_dev.data_ptr(), self._reward_kind, int(masked), int(act_seed), int(act_counter),
                     a_ptr, d_ptr, flags.data_ptr(), last.data_ptr()), "rollout")
                 if on_device:  # the slot may be overwritten once this rollout has consumed it
@@ -773,15 +819,43 @@ class VecGame:
                     self._sched_pending_slot["free"] = ev
             if kernel_events is not None:
                 kernel_events[1].record(torch.cuda.current_stream(dev))
-            if not fast and not on_device:  # the staging slot may be refilled once this launch has read it
-                slot[3].record(torch.cuda.current_stream(dev))
+            roll_ev = None
+            if (not fast and not on_device and staged) or finish_ids == "deferred":
+                # ONE marker per rollout, right after its kernel: it frees the pinned buffers the launch
+                # read and is what a deferred id scan waits for (every marker costs GPU time between kernels)
+                if self._roll_ev is None:
+                    self._roll_ev = [torch.cuda.Event() for _ in range(len(self._spin))]
+                roll_ev = self._roll_ev[self._roll_i]
+                self._roll_i = (self._roll_i + 1) % len(self._roll_ev)
+                roll_ev.record(torch.cuda.current_stream(dev))
+                if not fast and not on_device:
+                    for ps in staged:
+                        ps[1] = roll_ev
             step_resets = None
             if finish_ids:
                 step_resets = torch.empty((N,), dtype=torch.int32, device=dev)
                 scratch = torch.empty((int(L.ml2048_rollout_scratch_ints(M, N)),), dtype=torch.int32, device=dev)
+                if finish_ids == "deferred":
+                    # the rollout kernel reads neither ids nor the game counter, so the id scan of this
+                    # rollout may run beside the NEXT rollout's kernel: a side stream, in order with the
+                    # previous scans, joined by whatever touches ids next (join_ids)
+                    main = torch.cuda.current_stream(dev)
+                    if self._ids_stream is None:
+                        self._ids_stream = torch.cuda.Stream(device=dev)
+                        self._ids_done = torch.cuda.Event()
+                    side = self._ids_stream
+                    side.wait_event(roll_ev)
+                    for buf in (flags, last, step_resets, scratch):  # allocated on `main`, used on `side`
+                        buf.record_stream(side)
+                    ids_stream = side.cuda_stream
+                else:
+                    ids_stream = self._stream()
                 _lib.check(L.ml2048_rollout_finish_ids(
-                    self._stream(), M, self._st(), N, flags.data_ptr(), last.data_ptr(),
+                    ids_stream, M, self._st(), N, flags.data_ptr(), last.data_ptr(),
                     self._game_count_dev.data_ptr(), step_resets.data_ptr(), scratch.data_ptr()), "rollout_finish_ids")
+                if finish_ids == "deferred":
+                    self._ids_done.record(side)
+                    self._ids_pending = True
         # every temporary above was allocated on the launch stream, so the caching allocator's
         # stream-ordered reuse keeps them valid until the kernels have consumed them
         return {"actions": actions, "digests": dig, "step_resets": step_resets,

@@ -423,6 +423,35 @@ def test_device_schedule_rollouts_equal_host_schedule_rollouts(amd):
     assert a.digest() == b.digest()
 
 
+def test_deferred_id_scan_equals_inline(amd):
+    """rollout(finish_ids="deferred") (id scan on a side stream, overlapped with the next rollout) leaves
+    the same ids, game counter, per-step re-deal counts and records as the inline scan - also when the
+    per-step API, a differently sized rollout or an inline rollout follows."""
+    M = 8192
+    a = amd.VecGame(M, "normal", schedule="host-async")
+    b = amd.VecGame(M, "normal", schedule="host")
+    a.reset(404)
+    b.reset(404)
+    act = np.random.default_rng(9).integers(0, 4, size=M)
+    for k, n in enumerate((128, 128, 32, 200, 128)):
+        oa = a.rollout(n, masked=True, act_seed=3, act_counter=500 * k, finish_ids="deferred")
+        ob = b.rollout(n, masked=True, act_seed=3, act_counter=500 * k)
+        if k == 1:  # two deferred scans back to back, then the per-step API (which numbers new games)
+            for env in (a, b):
+                env.prepare()
+                env.step(act)
+        if k == 3:
+            a.join_ids()
+            assert np.array_equal(oa["step_resets"].cpu().numpy(), ob["step_resets"].cpu().numpy())
+            oa = a.rollout(64, masked=False, act_seed=4)  # an inline scan right after a deferred one
+            ob = b.rollout(64, masked=False, act_seed=4)
+            assert np.array_equal(oa["step_resets"].cpu().numpy(), ob["step_resets"].cpu().numpy())
+    assert np.array_equal(a.game_id.cpu().numpy(), b.game_id.cpu().numpy())
+    assert a._game_count == b._game_count
+    assert a._data.tobytes() == b._data.tobytes()
+    assert a.digest() == b.digest()
+
+
 def test_async_host_schedule_equals_sync(amd):
     """schedule='host-async' (native producer thread drawing ahead) == schedule='host', including
     switching to the per-step API in between (the drawn-ahead schedules are then discarded)."""

@@ -4,18 +4,21 @@ k_rollout launch (end of the previous kernel on the device -> start of k_rollout
     python tools/trace_gaps.py <dir containing *_kernel_trace.csv>
 """
 import csv
+import os
+import re
 import glob
 import statistics as st
 import sys
 
-f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[0]
+f = max(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
 rows = []
 for r in csv.DictReader(open(f)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 names = {}
 for s, e, n in rows:
-    short = n.split("(")[0].split("<")[0].split("::")[-1]
+    m = re.search(r"(k_[a-z_0-9]+|__amd_rocclr_[A-Za-z]+|[a-z_]+_kernel)", n)
+    short = m.group(1) if m else n[:40]
     names.setdefault(short, []).append(e - s)
 for n, d in sorted(names.items(), key=lambda kv: -sum(kv[1])):
     print(f"{n:28s} n={len(d):6d} avg {st.mean(d)/1e3:9.2f} us  med {st.median(d)/1e3:9.2f} us  total {sum(d)/1e6:9.3f} ms")
