@@ -387,6 +387,51 @@ ML_HD bool step_pre_lite(StepRegs &s, uint32_t action, int reward_kind, uint32_t
     return true;
 }
 
+// ---- the same step without a maintained valid-action mask ---------------------------------------
+// For uniform (unmasked) sampling nothing reads the mask between steps: an action is valid exactly
+// when the move changes the board, and `terminated` (= no valid action, :735-736) only needs "board
+// full and no two equal neighbours" - a board with a tile and an empty cell always has a move.  A
+// fused rollout may therefore skip valid_actions() every step and derive valid / prev_valid once at
+// the end, PROVIDED the stored mask is consistent with the stored board when it starts
+// (valid_consistent()); callers fall back to the eager form otherwise.
+ML_HD bool valid_consistent(const Board &b, uint32_t valid) { return valid_actions(b) == valid; }
+
+ML_HD bool board_differs(const Board &a, const Board &b) {
+    return ((a.r[0] ^ b.r[0]) | (a.r[1] ^ b.r[1]) | (a.r[2] ^ b.r[2]) | (a.r[3] ^ b.r[3])) != 0u;
+}
+
+// == (valid_actions(b) == 0) for every board with at least one tile
+ML_HD uint32_t no_move_left(const Board &b) {
+    const uint32_t all_nz = (b.r[0] + 0x7F7F7F7Fu) & (b.r[1] + 0x7F7F7F7Fu) & (b.r[2] + 0x7F7F7F7Fu) &
+                            (b.r[3] + 0x7F7F7F7Fu) & 0x80808080u;
+    uint32_t eq = 0; // 0x80 wherever two neighbours hold the same byte (only meaningful on a full board)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) eq |= z_bytes(b.r[i] ^ (b.r[i] >> 8)) & 0x00808080u;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) eq |= z_bytes(b.r[i] ^ b.r[i + 1]);
+    return (all_nz == 0x80808080u && eq == 0u) ? 1u : 0u;
+}
+
+// step_pre_lite whose validity test is "the move changes the board" (s.valid is neither read nor
+// written); pair with step_post_lazy
+ML_HD bool step_pre_lazy(StepRegs &s, uint32_t action, int reward_kind, uint32_t &mexp_first,
+                         uint32_t &mexp_second) {
+    const Board prev = s.board;
+    const MoveResult mv = move_board(prev, action & 3u);
+    if (action >= 4u || !board_differs(mv.board, prev)) return false;
+    MergeStats st;
+    merge_sums(mv.mexp_first, mv.mexp_second, reward_kind, st.sum_value, st.sum_rank, st.count);
+    mexp_first = mv.mexp_first;
+    mexp_second = mv.mexp_second;
+    s.board = mv.board;
+    s.step += 1;
+    s.reward = (float)reward_value(reward_kind, mv.board, prev, st);
+    s.score = (float)((double)s.score + (double)st.sum_value);
+    return true;
+}
+
+ML_HD void step_post_lazy(StepRegs &s) { s.terminated = no_move_left(s.board); }
+
 ML_HD void step_post(StepRegs &s) {
     s.valid = valid_actions(s.board);
     s.terminated = s.valid == 0u;

@@ -7,6 +7,7 @@
 // The one-hot encoder alone uses the wave-per-board mapping: the fp32 one-hot of one board is
 // exactly 64 lanes x 16 B, one dwordx4 store per lane per board.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <rocrand/rocrand_kernel.h>
 
 #include <stdarg.h>
@@ -776,116 +777,138 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
             rs1 = schedule[3 * j1 + 2];
         }
     }
-    for (int t0 = 0; t0 < N; t0 += kFlagChunk) {
-        const int t1 = t0 + kFlagChunk < N ? t0 + kFlagChunk : N;
-        for (int t = t0; t < t1; ++t) {
-            // table mode: the pre-drawn host schedule; fast mode: rocRAND Philox words keyed
-            // (spawn_seed; board; 2*(counter0+t) for the deal, +1 for the step) as the per-step API does
-            uint32_t two_mask = n_two_mask;
-            uint32_t perm_p = n_perm_p;
-            uint32_t perm_s[4] = {n_perm_s[0], n_perm_s[1], n_perm_s[2], n_perm_s[3]};
-            if (!FAST) {
-                const uint8_t *tab1 = perm_epochs + (int64_t)e1 * (ML2048_RAND_SIZE * 16);
-                if (VPF) { // requests for step t+1, consumed one iteration later
-                    n_two_mask = two_masks[e1];
-                    n_perm_p = load_perm_head(tab1, rp1 + idx_base + ii);
-                    load_perm_row(tab1, rs1 + idx_base + ii, n_perm_s);
-                } else {
-                    two_mask = two_masks[e1];
-                    perm_p = load_perm_head(tab1, rp1 + idx_base + ii);
-                    load_perm_row(tab1, rs1 + idx_base + ii, perm_s);
+    // Uniform (unmasked) sampling never reads the valid-action mask between steps, so when every board of
+    // this wave starts with a mask that is consistent with its board, the loop runs in its LAZY form:
+    // validity = "the move changes the board", terminated = "full and no equal neighbours"
+    // (board_ops.hpp step_pre_lazy / no_move_left), and valid / prev_valid are derived once, after the last
+    // step.  ~70 fewer VALU operations per board-step; identical results (tests/test_host_ops.py,
+    // tests/test_gpu_parity.py).  The optional outputs need the mask every step: always eager.
+    const bool lazy = !EXTRAS && !masked && __all(valid_consistent(s.board, s.valid) ? 1 : 0);
+    auto run_steps = [&](auto lazy_tag) {
+        constexpr bool LAZY = decltype(lazy_tag)::value;
+        for (int t0 = 0; t0 < N; t0 += kFlagChunk) {
+            const int t1 = t0 + kFlagChunk < N ? t0 + kFlagChunk : N;
+            for (int t = t0; t < t1; ++t) {
+                // table mode: the pre-drawn host schedule; fast mode: rocRAND Philox words keyed
+                // (spawn_seed; board; 2*(counter0+t) for the deal, +1 for the step) as the per-step API does
+                uint32_t two_mask = n_two_mask;
+                uint32_t perm_p = n_perm_p;
+                uint32_t perm_s[4] = {n_perm_s[0], n_perm_s[1], n_perm_s[2], n_perm_s[3]};
+                if (!FAST) {
+                    const uint8_t *tab1 = perm_epochs + (int64_t)e1 * (ML2048_RAND_SIZE * 16);
+                    if (VPF) { // requests for step t+1, consumed one iteration later
+                        n_two_mask = two_masks[e1];
+                        n_perm_p = load_perm_head(tab1, rp1 + idx_base + ii);
+                        load_perm_row(tab1, rs1 + idx_base + ii, n_perm_s);
+                    } else {
+                        two_mask = two_masks[e1];
+                        perm_p = load_perm_head(tab1, rp1 + idx_base + ii);
+                        load_perm_row(tab1, rs1 + idx_base + ii, perm_s);
+                    }
+                    const int j2 = t + 1 + VPF < N ? t + 1 + VPF : N - 1;
+                    const uint32_t e2r = (uint32_t)schedule[3 * j2 + 0];
+                    e1 = (int)(e2r < e_last ? e2r : e_last);
+                    rp1 = schedule[3 * j2 + 1];
+                    rs1 = schedule[3 * j2 + 2];
                 }
-                const int j2 = t + 1 + VPF < N ? t + 1 + VPF : N - 1;
-                const uint32_t e2r = (uint32_t)schedule[3 * j2 + 0];
-                e1 = (int)(e2r < e_last ? e2r : e_last);
-                rp1 = schedule[3 * j2 + 1];
-                rs1 = schedule[3 * j2 + 2];
-            }
 
-            // ---- prepare (game_numba.py:619-658)
-            const bool deal = s.terminated != 0;
-            const unsigned long long dealt = __ballot(deal && live);
-            if (lane == 0) flag_park[threadIdx.x >> 6][t - t0] = dealt;
-            if (deal) {
-                clear_regs(s);
-                invalid = 0;
-                mexp_first = mexp_second = 0;
-                merged_stale = true;
-                if (FAST) {
-                    uint32_t w4[4];
-                    rocrand_words(spawn_seed, 2ull * (spawn_counter0 + (uint64_t)t), (uint64_t)(idx_base + ii), w4);
-                    spawn_counter(s.board, w4[0], w4[1], thr);
-                    spawn_counter(s.board, w4[2], w4[3], thr);
+                // ---- prepare (game_numba.py:619-658)
+                const bool deal = s.terminated != 0;
+                const unsigned long long dealt = __ballot(deal && live);
+                if (lane == 0) flag_park[threadIdx.x >> 6][t - t0] = dealt;
+                if (deal) {
+                    clear_regs(s);
+                    invalid = 0;
+                    mexp_first = mexp_second = 0;
+                    merged_stale = true;
+                    if (FAST) {
+                        uint32_t w4[4];
+                        rocrand_words(spawn_seed, 2ull * (spawn_counter0 + (uint64_t)t), (uint64_t)(idx_base + ii), w4);
+                        spawn_counter(s.board, w4[0], w4[1], thr);
+                        spawn_counter(s.board, w4[2], w4[3], thr);
+                    } else {
+                        const uint32_t head[4] = {perm_p, 0, 0, 0};
+                        deal_table(s.board, head, two_mask);
+                    }
+                    if (!LAZY) s.valid = valid_actions(s.board);
+                    last = t;
+                }
+                // ---- sample (policy/random.py:17-27)
+                const uint64_t tt = act_counter0 + (uint64_t)t;
+                if (t > 0 && (tt & 3ull) == 0) {
+                    rocrand_state_philox4x32_10 rs;
+                    rocrand_init(act_seed, (uint64_t)(idx_base + ii), tt, &rs);
+                    const uint4 v = rocrand4(&rs);
+                    aw[0] = v.x; aw[1] = v.y; aw[2] = v.z; aw[3] = v.w;
+                }
+                const uint32_t word = aw[0];
+                aw[0] = aw[1]; aw[1] = aw[2]; aw[2] = aw[3];
+                uint32_t cnt = 4;
+                const uint32_t action = LAZY ? (word & 3u) : pick_action(s.valid, word, masked, cnt);
+                if (EXTRAS && actions_out && live) actions_out[(int64_t)t * M + i] = (uint8_t)action;
+                // ---- step (game_numba.py:660-738)
+                prev_board = s.board;
+                if (!LAZY) prev_valid = s.valid;
+                if (LAZY ? step_pre_lazy(s, action, KIND, mexp_first, mexp_second)
+                         : step_pre_lite(s, action, KIND, mexp_first, mexp_second)) {
+                    merged_stale = true;
+                    if (FAST) {
+                        uint32_t w4[4];
+                        rocrand_words(spawn_seed, 2ull * (spawn_counter0 + (uint64_t)t) + 1ull, (uint64_t)(idx_base + ii), w4);
+                        spawn_counter(s.board, w4[0], w4[1], thr);
+                    } else {
+                        spawn_table(s.board, perm_s, two_mask, 1);
+                    }
+                    if (LAZY) step_post_lazy(s); else step_post(s);
+                    invalid = 0;
                 } else {
-                    const uint32_t head[4] = {perm_p, 0, 0, 0};
-                    deal_table(s.board, head, two_mask);
+                    invalid = 1;
                 }
-                s.valid = valid_actions(s.board);
-                last = t;
-            }
-            // ---- sample (policy/random.py:17-27)
-            const uint64_t tt = act_counter0 + (uint64_t)t;
-            if (t > 0 && (tt & 3ull) == 0) {
-                rocrand_state_philox4x32_10 rs;
-                rocrand_init(act_seed, (uint64_t)(idx_base + ii), tt, &rs);
-                const uint4 v = rocrand4(&rs);
-                aw[0] = v.x; aw[1] = v.y; aw[2] = v.z; aw[3] = v.w;
-            }
-            const uint32_t word = aw[0];
-            aw[0] = aw[1]; aw[1] = aw[2]; aw[2] = aw[3];
-            uint32_t cnt;
-            const uint32_t action = pick_action(s.valid, word, masked, cnt);
-            if (EXTRAS && actions_out && live) actions_out[(int64_t)t * M + i] = (uint8_t)action;
-            // ---- step (game_numba.py:660-738)
-            prev_board = s.board;
-            prev_valid = s.valid;
-            if (step_pre_lite(s, action, KIND, mexp_first, mexp_second)) {
-                merged_stale = true;
-                if (FAST) {
-                    uint32_t w4[4];
-                    rocrand_words(spawn_seed, 2ull * (spawn_counter0 + (uint64_t)t) + 1ull, (uint64_t)(idx_base + ii), w4);
-                    spawn_counter(s.board, w4[0], w4[1], thr);
-                } else {
-                    spawn_table(s.board, perm_s, two_mask, 1);
+                // ---- optional trajectory: this step's transition into [N][M] buffers with the REPLAY_SPEC
+                //      dtypes (replay.py:10-20), i.e. what N x ml2048_record_transition would write
+                if (EXTRAS && live) {
+                    const int64_t o = (int64_t)t * M + i;
+                    if (traj.state) reinterpret_cast<uint4 *>(traj.state)[o] = make_uint4(prev_board.r[0], prev_board.r[1], prev_board.r[2], prev_board.r[3]);
+                    if (traj.next_state) reinterpret_cast<uint4 *>(traj.next_state)[o] = make_uint4(s.board.r[0], s.board.r[1], s.board.r[2], s.board.r[3]);
+                    if (traj.valid_actions) reinterpret_cast<uint32_t *>(traj.valid_actions)[o] = prev_valid;
+                    if (traj.next_valid_actions) reinterpret_cast<uint32_t *>(traj.next_valid_actions)[o] = s.valid;
+                    if (traj.action) traj.action[o] = (int8_t)action;
+                    if (traj.action_log_prob) traj.action_log_prob[o] = neg_log_count(cnt);
+                    if (traj.reward) traj.reward[o] = s.reward;
+                    if (traj.step) traj.step[o] = s.step;
+                    if (traj.terminated) traj.terminated[o] = s.terminated != 0;
                 }
-                step_post(s);
-                invalid = 0;
-            } else {
-                invalid = 1;
-            }
-            // ---- optional trajectory: this step's transition into [N][M] buffers with the REPLAY_SPEC
-            //      dtypes (replay.py:10-20), i.e. what N x ml2048_record_transition would write
-            if (EXTRAS && live) {
-                const int64_t o = (int64_t)t * M + i;
-                if (traj.state) reinterpret_cast<uint4 *>(traj.state)[o] = make_uint4(prev_board.r[0], prev_board.r[1], prev_board.r[2], prev_board.r[3]);
-                if (traj.next_state) reinterpret_cast<uint4 *>(traj.next_state)[o] = make_uint4(s.board.r[0], s.board.r[1], s.board.r[2], s.board.r[3]);
-                if (traj.valid_actions) reinterpret_cast<uint32_t *>(traj.valid_actions)[o] = prev_valid;
-                if (traj.next_valid_actions) reinterpret_cast<uint32_t *>(traj.next_valid_actions)[o] = s.valid;
-                if (traj.action) traj.action[o] = (int8_t)action;
-                if (traj.action_log_prob) traj.action_log_prob[o] = neg_log_count(cnt);
-                if (traj.reward) traj.reward[o] = s.reward;
-                if (traj.step) traj.step[o] = s.step;
-                if (traj.terminated) traj.terminated[o] = s.terminated != 0;
-            }
-            if (EXTRAS && digests_out) {
-                if (merged_stale) {
-                    merge_buckets(mexp_first, mexp_second, s.merged);
-                    merged_stale = false;
+                if (EXTRAS && digests_out) {
+                    if (merged_stale) {
+                        merge_buckets(mexp_first, mexp_second, s.merged);
+                        merged_stale = false;
+                    }
+                    uint64_t h = 0;
+                    if (live)
+                        h = board_digest((uint64_t)(idx_base + i), s.board, s.merged, s.valid, s.terminated, invalid,
+                                         s.step, 0, __float_as_uint(s.score), __float_as_uint(s.reward), 0);
+                    h = wave_sum_u64(h);
+                    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(digests_out + t), (unsigned long long)h);
                 }
-                uint64_t h = 0;
-                if (live)
-                    h = board_digest((uint64_t)(idx_base + i), s.board, s.merged, s.valid, s.terminated, invalid,
-                                     s.step, 0, __float_as_uint(s.score), __float_as_uint(s.reward), 0);
-                h = wave_sum_u64(h);
-                if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(digests_out + t), (unsigned long long)h);
             }
+            // flush this chunk's re-deal flags (wave-private LDS row: a wave-scope fence is enough)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int q = lane; q < t1 - t0; q += 64)
+                reset_flags[(int64_t)(t0 + q) * flag_words + wave_global] = flag_park[threadIdx.x >> 6][q];
         }
-        // flush this chunk's re-deal flags (wave-private LDS row: a wave-scope fence is enough)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int q = lane; q < t1 - t0; q += 64)
-            reset_flags[(int64_t)(t0 + q) * flag_words + wave_global] = flag_park[threadIdx.x >> 6][q];
+    };
+    if constexpr (EXTRAS) {
+        run_steps(std::false_type{});
+    } else {
+        if (!lazy) {
+            run_steps(std::false_type{});
+        } else {
+            run_steps(std::true_type{});
+            s.valid = valid_actions(s.board);
+            prev_valid = valid_actions(prev_board);
+        }
     }
     if (merged_stale) merge_buckets(mexp_first, mexp_second, s.merged);
 

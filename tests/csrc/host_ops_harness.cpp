@@ -51,6 +51,26 @@ void h_valid(const uint8_t *boards, int64_t n, uint8_t *valid, uint16_t *empties
     }
 }
 
+// the lazy-mask forms against the eager ones: no_move_left == (valid_actions == 0); a move changes the
+// board exactly when its valid bit is set.  Returns the number of disagreements.
+int64_t h_lazy_mask_check(const uint8_t *boards, int64_t n) {
+    int64_t bad = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        Board b;
+        memcpy(b.r, boards + 16 * i, 16);
+        const uint32_t v = valid_actions(b);
+        const bool has_tile = (b.r[0] | b.r[1] | b.r[2] | b.r[3]) != 0;
+        if (has_tile && no_move_left(b) != (v == 0 ? 1u : 0u)) ++bad;
+        for (uint32_t a = 0; a < 4; ++a) {
+            const MoveResult mv = move_board(b, a);
+            const bool valid_bit = ((v >> (8 * a)) & 0xFFu) != 0;
+            if (board_differs(mv.board, b) != valid_bit) ++bad;
+        }
+        if (!valid_consistent(b, v)) ++bad;
+    }
+    return bad;
+}
+
 void h_transpose(const uint8_t *in, uint8_t *out) {
     Board b;
     memcpy(b.r, in, 16);

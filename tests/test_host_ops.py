@@ -30,6 +30,8 @@ def H():
     L.h_move.argtypes = [vp, i64, vp, vp, vp, vp]
     L.h_valid.argtypes = [vp, i64, vp, vp, vp]
     L.h_transpose.argtypes = [vp, vp]
+    L.h_lazy_mask_check.argtypes = [vp, i64]
+    L.h_lazy_mask_check.restype = i64
     L.h_step.argtypes = [vp, i64, i64, vp, vp, vp, i32, dbl, i64, vp, vp]
     L.h_prepare.argtypes = [vp, i64, i64, i64, vp, vp, dbl, vp]
     L.h_prepare.restype = i64
@@ -115,6 +117,19 @@ def test_valid_empties_maxcell_vs_oracle(H, oracle):
     exp_empty = ((boards == 0) * (1 << np.arange(16))).sum(axis=1)
     assert np.array_equal(exp_empty.astype(np.uint16), empties)
     assert np.array_equal(boards.max(axis=1), maxcell)
+
+
+def test_lazy_mask_forms_agree_with_the_eager_mask(H):
+    """What the fused rollout uses when nothing reads the mask between steps (uniform sampling):
+    `terminated` from "full and no equal neighbours", validity from "the move changes the board"."""
+    rng = np.random.default_rng(16)
+    n = 200000
+    dense = rng.integers(1, 5, size=(n // 2, 16)).astype(np.uint8)       # full boards, many dead ends
+    dense[rng.random(dense.shape) < 0.03] = 0
+    checker = (np.add.outer(np.arange(4), np.arange(4)) % 2 + 1).reshape(1, 16).astype(np.uint8)
+    boards = np.concatenate([_random_boards(rng, n // 2 - 3), dense, checker, checker[:, ::-1] * 3,
+                             np.full((1, 16), 17, np.uint8)])
+    assert H.h_lazy_mask_check(_p(boards), boards.shape[0]) == 0
 
 
 def _rec(oracle, M):
