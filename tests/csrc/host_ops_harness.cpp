@@ -71,6 +71,21 @@ int64_t h_lazy_mask_check(const uint8_t *boards, int64_t n) {
     return bad;
 }
 
+// the four-lines-at-once move against four separate line pushes; returns the number of differences
+int64_t h_move_forms_check(const uint8_t *boards, int64_t n) {
+    int64_t bad = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        Board b;
+        memcpy(b.r, boards + 16 * i, 16);
+        for (uint32_t a = 0; a < 4; ++a) {
+            const MoveResult x = move_board(b, a), y = move_board_by_lines(b, a);
+            if (memcmp(x.board.r, y.board.r, 16) != 0 || x.mexp_first != y.mexp_first || x.mexp_second != y.mexp_second)
+                ++bad;
+        }
+    }
+    return bad;
+}
+
 void h_transpose(const uint8_t *in, uint8_t *out) {
     Board b;
     memcpy(b.r, in, 16);

@@ -30,6 +30,8 @@ def H():
     L.h_move.argtypes = [vp, i64, vp, vp, vp, vp]
     L.h_valid.argtypes = [vp, i64, vp, vp, vp]
     L.h_transpose.argtypes = [vp, vp]
+    L.h_move_forms_check.argtypes = [vp, i64]
+    L.h_move_forms_check.restype = i64
     L.h_lazy_mask_check.argtypes = [vp, i64]
     L.h_lazy_mask_check.restype = i64
     L.h_step.argtypes = [vp, i64, i64, vp, vp, vp, i32, dbl, i64, vp, vp]
@@ -117,6 +119,23 @@ def test_valid_empties_maxcell_vs_oracle(H, oracle):
     exp_empty = ((boards == 0) * (1 << np.arange(16))).sum(axis=1)
     assert np.array_equal(exp_empty.astype(np.uint16), empties)
     assert np.array_equal(boards.max(axis=1), maxcell)
+
+
+def test_move_all_lines_at_once_equals_line_by_line(H):
+    """move_board (four lines bytewise in four cell words) == four push_line calls, board and merge
+    exponents, for every one of the 18^4 lines placed in each of the four line positions of a board (all
+    four directions) and for random boards up to exponent 17."""
+    import itertools
+
+    lines = np.array(list(itertools.product(range(18), repeat=4)), dtype=np.uint8)   # 104976 x 4
+    rng = np.random.default_rng(3)
+    boards = rng.integers(0, 18, size=(lines.shape[0], 4, 4)).astype(np.uint8)
+    boards[np.arange(lines.shape[0]), np.arange(lines.shape[0]) % 4, :] = lines       # as a row
+    cols = boards.copy().transpose(0, 2, 1).copy()                                      # and as a column
+    sparse = _random_boards(rng, 100000)
+    dense = rng.integers(1, 4, size=(100000, 16)).astype(np.uint8)
+    allb = np.ascontiguousarray(np.concatenate([boards.reshape(-1, 16), cols.reshape(-1, 16), sparse, dense]))
+    assert H.h_move_forms_check(_p(allb), allb.shape[0]) == 0
 
 
 def test_lazy_mask_forms_agree_with_the_eager_mask(H):
