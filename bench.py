@@ -151,6 +151,9 @@ def main():
     import torch
 
     import ml2048_amd as amd
+    from ml2048_amd import _lib
+
+    L = _lib.load()
     from ml2048_amd import build as hip_build
 
     if int(os.environ.get("LOCAL_RANK", "0")) == 0:
@@ -209,13 +212,17 @@ def main():
 
     def bench_step(timed: bool):
         if args.mode in ("fused", "fused-traj"):
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if timed else None
-            env.rollout(N, masked=bool(args.masked), act_seed=7 + rank, act_counter=counter[0], kernel_events=ev,
+            tm = None
+            if timed:  # HIP event pair attached to the kernel's dispatch (hipExtLaunchKernel), on its stream
+                import ctypes as C
+                tm = C.c_void_p()
+                _lib.check(L.ml2048_timer_create(C.byref(tm)), "timer_create")
+            env.rollout(N, masked=bool(args.masked), act_seed=7 + rank, act_counter=counter[0], kernel_timer=tm,
                         prefetch_next=bool(args.prefetch), trajectory=traj,
                         finish_ids="deferred" if args.ids == "deferred" else True)
             counter[0] += N
-            if ev:
-                kern_ms.append(ev)
+            if tm is not None:
+                kern_ms.append(tm)
         else:
             for _ in range(N):
                 env.prepare_torch()
@@ -248,7 +255,14 @@ def main():
     # dominant kernel duration, HIP events on the launch stream
     roofline = None
     if args.mode in ("fused", "fused-traj") and kern_ms:
-        avg_ms = sum(a.elapsed_time(b) for a, b in kern_ms) / len(kern_ms)
+        import ctypes as C
+        vals = []
+        for tm in kern_ms:
+            ms = C.c_float(0.0)
+            _lib.check(L.ml2048_timer_elapsed_ms(tm, C.byref(ms)), "timer_elapsed_ms")
+            vals.append(float(ms.value))
+            L.ml2048_timer_destroy(tm)
+        avg_ms = sum(vals) / len(vals)
         # fused-traj: the 54 B/board-step of REPLAY_SPEC transitions are really written
         alg_bytes = (54 if args.mode == "fused-traj" else BYTES_PER_BOARD_STEP) * M * N
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9

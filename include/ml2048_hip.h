@@ -257,6 +257,17 @@ int64_t ml2048_rollout_flag_words(int64_t M);
 int64_t ml2048_rollout_scratch_ints(int64_t M, int32_t N);
 
 /*
+ * Measurement only: a HIP event pair attached to the dispatch of the next ml2048_rollout* launch made
+ * by the calling thread (hipExtLaunchKernel start/stop events), i.e. the kernel's own duration as
+ * rocprofv3 reports it, without the marker packets that events recorded around a launch add.
+ * create -> arm (one-shot) -> launch -> elapsed_ms (synchronises on the stop event) -> destroy.
+ */
+int ml2048_timer_create(void **timer);
+int ml2048_timer_arm(void *timer);
+int ml2048_timer_elapsed_ms(void *timer, float *ms);
+void ml2048_timer_destroy(void *timer);
+
+/*
  * ml2048_rollout that ALSO uploads the next rollout's packed schedule: the same launch copies
  * next_nbytes (rounded up to 16) from next_src_host (pinned / registered host memory, 16-byte
  * aligned) to next_dst (device, 16-byte aligned, a buffer this launch does not read).  Stream order

@@ -7,6 +7,7 @@
 // The one-hot encoder alone uses the wave-per-board mapping: the fp32 one-hot of one board is
 // exactly 64 lanes x 16 B, one dwordx4 store per lane per board.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <type_traits>
 #include <rocrand/rocrand_kernel.h>
 
@@ -1290,6 +1291,57 @@ int ml2048_upload(void *stream, void *dst, const void *src_host, int64_t nbytes)
     return check_launch("ml2048_upload");
 }
 
+// ---- kernel timer: a HIP event pair attached to the rollout DISPATCH itself (hipExtLaunchKernel),
+// so that the measured interval is the kernel and nothing else (events recorded around a launch also
+// time two marker packets, ~4 % at C2) ---------------------------------------------------------------
+struct ml2048_timer_impl {
+    hipEvent_t start, stop;
+    bool used;
+};
+static thread_local ml2048_timer_impl *g_armed_timer = nullptr;
+
+int ml2048_timer_create(void **timer) {
+    if (!timer) return fail(ML2048_E_INVALID, "timer is NULL");
+    ml2048_timer_impl *t = new ml2048_timer_impl{nullptr, nullptr, false};
+    hipError_t e = hipEventCreate(&t->start);
+    if (e == hipSuccess) e = hipEventCreate(&t->stop);
+    if (e != hipSuccess) {
+        delete t;
+        fail(ML2048_E_INVALID, "hipEventCreate: %s", hipGetErrorString(e));
+        return (int)e; // > 0: a hipError_t, as everywhere in this ABI
+    }
+    *timer = t;
+    return 0;
+}
+
+int ml2048_timer_arm(void *timer) {
+    if (!timer) return fail(ML2048_E_INVALID, "timer is NULL");
+    g_armed_timer = (ml2048_timer_impl *)timer;
+    return 0;
+}
+
+int ml2048_timer_elapsed_ms(void *timer, float *ms) {
+    ml2048_timer_impl *t = (ml2048_timer_impl *)timer;
+    if (!t || !ms) return fail(ML2048_E_INVALID, "timer/ms is NULL");
+    if (!t->used) return fail(ML2048_E_INVALID, "timer was never attached to a launch");
+    hipError_t e = hipEventSynchronize(t->stop);
+    if (e == hipSuccess) e = hipEventElapsedTime(ms, t->start, t->stop);
+    if (e != hipSuccess) {
+        fail(ML2048_E_INVALID, "hipEventElapsedTime: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+void ml2048_timer_destroy(void *timer) {
+    ml2048_timer_impl *t = (ml2048_timer_impl *)timer;
+    if (!t) return;
+    if (g_armed_timer == t) g_armed_timer = nullptr;
+    (void)hipEventDestroy(t->start);
+    (void)hipEventDestroy(t->stop);
+    delete t;
+}
+
 static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
                           const uint8_t *perm_epochs, const uint32_t *two_masks, const int32_t *schedule, int32_t n_epochs,
                           int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0, uint8_t *actions_out,
@@ -1315,8 +1367,12 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
     const int64_t W = ml2048_rollout_flag_words(M);
     const uint64_t thr = two_threshold(two_prob);
     const bool extras = actions_out || digests_out || traj_or_null;
+    ml2048_timer_impl *const timer = g_armed_timer; // one-shot: bracket THIS dispatch with the armed timer's events
+    g_armed_timer = nullptr;
+    hipEvent_t ev_start = timer ? timer->start : nullptr, ev_stop = timer ? timer->stop : nullptr;
+    if (timer) timer->used = true;
 #define ML_LAUNCH2(K, F, X)                                                                                  \
-    hipLaunchKernelGGL((k_rollout<K, F, X>), grid, block, 0, s, *st, M, idx_base, N, perm_epochs, two_masks, \
+    hipExtLaunchKernelGGL((k_rollout<K, F, X>), grid, block, 0, s, ev_start, ev_stop, 0, *st, M, idx_base, N, perm_epochs, two_masks, \
                        schedule, n_epochs, masked, act_seed, act_counter0, actions_out, digests_out,         \
                        reset_flags, W,                                                                       \
                        last_reset, spawn_seed, spawn_counter0, thr, traj, (const uint4 *)up_src, (uint4 *)up_dst, up_n16, up_blocks)

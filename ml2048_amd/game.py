@@ -693,7 +693,7 @@ class VecGame:
     def rollout(self, n_steps: int, *, masked: bool = True, act_seed: int = 0, act_counter: int = 0,
                 record_actions: bool = False, digests: bool = False, finish_ids=True,
                 kernel_events: Optional[tuple] = None, prefetch_next: bool = False,
-                trajectory: Optional[dict] = None):
+                trajectory: Optional[dict] = None, kernel_timer=None):
         """N x {prepare; uniform-random actions; step} fused into one kernel launch, bit-exact
         with the per-step API on the same seeds (both spawn modes; spawn="rocrand" needs no host
         schedule and is purely GPU-bound).
@@ -702,6 +702,8 @@ class VecGame:
         uint64) | None, step_resets (N,) int32 | None.
         kernel_events: optional (start, end) torch.cuda.Event pair recorded on the launch stream
         immediately around the rollout kernel (bench.py times the dominant kernel with it).
+        kernel_timer: a handle from ml2048_timer_create; its event pair is attached to the rollout kernel's
+        dispatch itself (exact kernel duration, no marker packets; read it with ml2048_timer_elapsed_ms).
         finish_ids: True = number the re-dealt games (ordered ids, game counter, step_resets) on the launch
         stream right after the kernel; "deferred" = the same scan on a side stream, overlapped with whatever
         the launch stream does next (every method of this class waits for it before it touches ids; read
@@ -778,6 +780,8 @@ class VecGame:
         with self._dev_ctx():
             if kernel_events is not None:
                 kernel_events[0].record(torch.cuda.current_stream(dev))
+            if kernel_timer is not None:
+                _lib.check(L.ml2048_timer_arm(kernel_timer), "timer_arm")
             if trajectory is not None:
                 if fast or record_actions or digests:
                     raise ValueError("trajectory= is for table spawn mode, without record_actions/digests")
