@@ -268,28 +268,36 @@ int ml2048_timer_elapsed_ms(void *timer, float *ms);
 void ml2048_timer_destroy(void *timer);
 
 /*
- * ml2048_rollout that ALSO uploads the next rollout's packed schedule: the same launch copies
- * next_nbytes (rounded up to 16) from next_src_host (pinned / registered host memory, 16-byte
- * aligned) to next_dst (device, 16-byte aligned, a buffer this launch does not read).  Stream order
- * alone then guarantees the data is there for the next launch: a chain of fused rollouts needs no
- * copy stream and no event (the reference keeps its tables in host memory, game_numba.py:589-591,
- * so it has no counterpart to this copy).
+ * The pipelined form of ml2048_rollout: expanded tables + chained upload.
+ *  - perm_epochs is uint8[n_epochs][1024][32]: each row is the 16-byte permutation followed by its
+ *    INVERSE in board layout (byte c = position of cell c), which lets the kernel find the first
+ *    empty cell of the row with one shift per cell instead of probing 16 positions
+ *    (csrc/board_ops.hpp spawn_table_inv; same tile as _spawn2, game_numba.py:172-212).  Such tables are
+ *    produced by ml2048_upload / by the previous ml2048_rollout_chain (n_table_rows > 0).
+ *  - the same launch copies the NEXT rollout's packed schedule: next_nbytes (rounded up to 16) from
+ *    next_src_host (pinned / registered host memory, 16-byte aligned; its first next_table_rows x 16
+ *    bytes are plain permutation rows) to next_dst (device, 16-byte aligned, not read by this launch),
+ *    expanding those rows to the 32-byte form: next_dst receives next_table_rows x 32 bytes of tables
+ *    followed by the remaining bytes unchanged.  Stream order alone then guarantees the data is there
+ *    for the next launch: a chain of fused rollouts needs no copy stream and no event.  next_* = NULL/0/0:
+ *    no upload.  (The reference keeps its tables in host memory, game_numba.py:589-591: no counterpart.)
  */
 int ml2048_rollout_chain(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
                          const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,
                          const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed,
                          uint64_t act_counter0, uint64_t *reset_flags, int32_t *last_reset,
-                         const void *next_src_host, void *next_dst, int64_t next_nbytes);
+                         const void *next_src_host, void *next_dst, int64_t next_nbytes,
+                         int64_t next_table_rows);
 
 /*
  * Upload of a pre-drawn schedule: a copy KERNEL that reads device-accessible (pinned / registered)
- * host memory directly, so that the upload is an ordinary launch on `stream` (typically a side
- * stream, overlapped with the previous rollout) and involves neither the copy engine nor a host
- * wait.  dst: device, src_host: pinned host memory, both 16-byte aligned; nbytes is rounded up
- * to a multiple of 16 (both buffers must have that capacity).  The reference performs no such
- * copy: its tables never leave host memory (game_numba.py:589-591).
+ * host memory directly, so that the upload is an ordinary launch on `stream` and involves neither the
+ * copy engine nor a host wait.  dst: device, src_host: pinned host memory, both 16-byte aligned; nbytes
+ * is rounded up to a multiple of 16.  The first n_table_rows x 16 bytes are permutation rows and are
+ * expanded to the 32-byte form described above (dst then needs nbytes + 16 x n_table_rows bytes);
+ * n_table_rows = 0 is a plain copy.
  */
-int ml2048_upload(void *stream, void *dst, const void *src_host, int64_t nbytes);
+int ml2048_upload(void *stream, void *dst, const void *src_host, int64_t nbytes, int64_t n_table_rows);
 int ml2048_rollout(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
                    const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,
                    const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed,

@@ -339,6 +339,61 @@ ML_HD void spawn_table(Board &b, const uint32_t perm[4], uint32_t two_mask, int 
     }
 }
 
+// ---- the same spawn from the row's INVERSE permutation ------------------------------------------
+// inv[c] = position of cell c in the permutation row, laid out like the board (byte j of word k =
+// cell 4k+j).  Then  hits = OR over empty cells c of (1 << inv[c])  needs no per-position probing: one
+// SDWA shift per cell - byte j of the emptiness flags (0x80 / 0) shifted left by byte j of inv - and
+// an OR tree (32 VALU instead of ~72).  The winning position is ctz(hits); its cell is perm[position].
+ML_HD uint32_t shl_byte_by_byte(uint32_t flags, uint32_t amounts, int j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t out;
+    switch (j) { // v_lshlrev_b32 D = S1 << S0[4:0]: S0 = byte j of `amounts`, S1 = byte j of `flags`
+    case 0: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(out) : "v"(amounts), "v"(flags)); break;
+    case 1: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(out) : "v"(amounts), "v"(flags)); break;
+    case 2: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2" : "=v"(out) : "v"(amounts), "v"(flags)); break;
+    default: asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(out) : "v"(amounts), "v"(flags)); break;
+    }
+    return out;
+#else
+    return ((flags >> (8 * j)) & 0xFFu) << ((amounts >> (8 * j)) & 0x1Fu);
+#endif
+}
+
+// one tile (the step's spawn, count = 1); equals spawn_table(b, perm, two_mask, 1) when inv is the
+// inverse of perm
+ML_HD void spawn_table_inv(Board &b, const uint32_t perm[4], const uint32_t inv[4], uint32_t two_mask) {
+    uint32_t acc = 0; // bit 7 + i  <=>  the cell at position i of the row is empty
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t z = z_bytes(b.r[k]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc |= shl_byte_by_byte(z, inv[k], j);
+    }
+    const uint32_t hits = acc >> 7;
+    if (hits == 0) return;
+    const uint32_t i = (uint32_t)__builtin_ctz(hits);
+    const uint64_t plo = (uint64_t)perm[0] | ((uint64_t)perm[1] << 32);
+    const uint64_t phi = (uint64_t)perm[2] | ((uint64_t)perm[3] << 32);
+    const uint64_t half = (i & 8u) ? phi : plo;
+    const uint32_t c = (uint32_t)(half >> (8u * (i & 7u))) & 0xFu;
+    set_cell(b, c, 2u - ubfe(two_mask, c, 1));
+}
+
+// inverse of one permutation row, in board layout (what the schedule upload computes per row)
+ML_HD void invert_perm_row(const uint32_t perm[4], uint32_t inv[4]) {
+    inv[0] = inv[1] = inv[2] = inv[3] = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t c = ubfe(perm[i >> 2], 8u * (i & 3), 4);
+        const uint32_t v = (uint32_t)i << ((c & 3u) * 8u);
+        const uint32_t d = c >> 2;
+        inv[0] |= (d == 0u) ? v : 0u;
+        inv[1] |= (d == 1u) ? v : 0u;
+        inv[2] |= (d == 2u) ? v : 0u;
+        inv[3] |= (d == 3u) ? v : 0u;
+    }
+}
+
 // the two tiles of a freshly dealt (empty) board: the first two entries of the permutation row
 // (VecGame.prepare's `_spawn2(..., 2)` on a zeroed record, game_numba.py:639-655)
 ML_HD void deal_table(Board &b, const uint32_t perm[4], uint32_t two_mask) {

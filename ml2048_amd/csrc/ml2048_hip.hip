@@ -97,6 +97,41 @@ __device__ __forceinline__ uint32_t load_perm_head(const uint8_t *randperm, int6
     return reinterpret_cast<const uint32_t *>(randperm)[(row & (ML2048_RAND_SIZE - 1)) * 4];
 }
 
+// INV tables: a row is 32 bytes - the permutation, then its inverse in board layout (board_ops.hpp
+// spawn_table_inv); ROW16 = uint4 units per row
+template <bool INV>
+__device__ __forceinline__ void load_table_row(const uint8_t *tab, int64_t row, uint32_t perm[4], uint32_t inv[4]) {
+    const uint4 *t = reinterpret_cast<const uint4 *>(tab);
+    const int64_t r = row & (ML2048_RAND_SIZE - 1);
+    if (INV) {
+        const uint4 v = t[2 * r], w = t[2 * r + 1];
+        perm[0] = v.x; perm[1] = v.y; perm[2] = v.z; perm[3] = v.w;
+        inv[0] = w.x; inv[1] = w.y; inv[2] = w.z; inv[3] = w.w;
+    } else {
+        const uint4 v = t[r];
+        perm[0] = v.x; perm[1] = v.y; perm[2] = v.z; perm[3] = v.w;
+    }
+}
+template <bool INV>
+__device__ __forceinline__ uint32_t load_table_head(const uint8_t *tab, int64_t row) {
+    return reinterpret_cast<const uint32_t *>(tab)[(row & (ML2048_RAND_SIZE - 1)) * (INV ? 8 : 4)];
+}
+
+// One 16-byte unit of a schedule upload.  The first `rows` units of the source are permutation rows:
+// each goes out as 32 bytes (the row, then its inverse); the rest (schedule, masks) is copied behind them.
+__device__ __forceinline__ void upload_unit(uint4 *dst, const uint4 *src, int64_t j, int64_t rows) {
+    const uint4 v = src[j];
+    if (j < rows) {
+        const uint32_t perm[4] = {v.x, v.y, v.z, v.w};
+        uint32_t inv[4];
+        invert_perm_row(perm, inv);
+        dst[2 * j] = v;
+        dst[2 * j + 1] = make_uint4(inv[0], inv[1], inv[2], inv[3]);
+    } else {
+        dst[j + rows] = v;
+    }
+}
+
 // rocRAND Philox4x32-10 device generator: words of (seed, subsequence = idx, offset = 4*counter)
 __device__ __forceinline__ void rocrand_words(uint64_t seed, uint64_t counter, uint64_t idx, uint32_t w[4]) {
     rocrand_state_philox4x32_10 s;
@@ -676,7 +711,7 @@ __global__ __launch_bounds__(kBlock) void k_digest(ml2048_state st, int64_t M, i
 // EXTRAS = false compiles the optional outputs (actions_out, digests_out, trajectory) out entirely:
 // with one wave per SIMD every taken branch costs an instruction-buffer refill, and a dozen
 // "pointer is NULL, skip" branches per step were ~10 % of the kernel (SQ_WAIT_ANY, profiles/).
-template <int KIND, bool FAST, bool EXTRAS>
+template <int KIND, bool FAST, bool EXTRAS, bool INV>
 __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, int64_t idx_base, int N,
                                                     const uint8_t *__restrict__ perm_epochs,
                                                     const uint32_t *__restrict__ two_masks,
@@ -688,7 +723,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                                                     int32_t *__restrict__ last_reset, uint64_t spawn_seed,
                                                     uint64_t spawn_counter0, uint64_t thr, ml2048_traj traj,
                                                     const uint4 *__restrict__ up_src, uint4 *__restrict__ up_dst,
-                                                    int64_t up_n16, unsigned up_blocks) {
+                                                    int64_t up_n16, unsigned up_blocks, int64_t up_rows) {
     // re-deal flags of up to kFlagChunk steps are parked in LDS so that the step loop holds no global
     // store (its acknowledgement would share the vmcnt queue with the prefetched loads)
     __shared__ unsigned long long flag_park[kBlock / 64][kFlagChunk];
@@ -708,7 +743,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
     // are gone after a few microseconds, so no board ever waits for a PCIe read.
     if (up_blocks > 0 && blockIdx.x >= gridDim.x - up_blocks) {
         const int64_t first = (int64_t)(blockIdx.x - (gridDim.x - up_blocks)) * kBlock + threadIdx.x;
-        for (int64_t j = first; j < up_n16; j += (int64_t)up_blocks * kBlock) up_dst[j] = up_src[j];
+        for (int64_t j = first; j < up_n16; j += (int64_t)up_blocks * kBlock) upload_unit(up_dst, up_src, j, up_rows);
         return;
     }
 
@@ -757,7 +792,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
     int e1 = 0;
     int64_t rp1 = 0, rs1 = 0;             // schedule entry of step t + VPF
     uint32_t n_two_mask = 0, n_perm_p = 0; // VPF: data of step t, in flight since the previous iteration
-    uint32_t n_perm_s[4] = {0, 0, 0, 0};
+    uint32_t n_perm_s[4] = {0, 0, 0, 0}, n_inv_s[4] = {0, 0, 0, 0};
+    constexpr int64_t kEpochBytes = (int64_t)ML2048_RAND_SIZE * (INV ? 32 : 16);
     // an epoch index is clamped to the tables that exist: a corrupted schedule then yields wrong
     // boards, never an out-of-bounds read (rows are already taken modulo the table size)
     const uint32_t e_last = (uint32_t)(n_epochs - 1);
@@ -767,10 +803,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
         rp1 = schedule[1];
         rs1 = schedule[2];
         if (VPF) {
-            const uint8_t *tab0 = perm_epochs + (int64_t)e1 * (ML2048_RAND_SIZE * 16);
+            const uint8_t *tab0 = perm_epochs + (int64_t)e1 * kEpochBytes;
             n_two_mask = two_masks[e1];
-            n_perm_p = load_perm_head(tab0, rp1 + idx_base + ii);
-            load_perm_row(tab0, rs1 + idx_base + ii, n_perm_s);
+            n_perm_p = load_table_head<INV>(tab0, rp1 + idx_base + ii);
+            load_table_row<INV>(tab0, rs1 + idx_base + ii, n_perm_s, n_inv_s);
             const int j1 = N > 1 ? 1 : 0;
             const uint32_t e1r = (uint32_t)schedule[3 * j1 + 0];
             e1 = (int)(e1r < e_last ? e1r : e_last);
@@ -795,16 +831,17 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                 uint32_t two_mask = n_two_mask;
                 uint32_t perm_p = n_perm_p;
                 uint32_t perm_s[4] = {n_perm_s[0], n_perm_s[1], n_perm_s[2], n_perm_s[3]};
+                uint32_t inv_s[4] = {n_inv_s[0], n_inv_s[1], n_inv_s[2], n_inv_s[3]};
                 if (!FAST) {
-                    const uint8_t *tab1 = perm_epochs + (int64_t)e1 * (ML2048_RAND_SIZE * 16);
+                    const uint8_t *tab1 = perm_epochs + (int64_t)e1 * kEpochBytes;
                     if (VPF) { // requests for step t+1, consumed one iteration later
                         n_two_mask = two_masks[e1];
-                        n_perm_p = load_perm_head(tab1, rp1 + idx_base + ii);
-                        load_perm_row(tab1, rs1 + idx_base + ii, n_perm_s);
+                        n_perm_p = load_table_head<INV>(tab1, rp1 + idx_base + ii);
+                        load_table_row<INV>(tab1, rs1 + idx_base + ii, n_perm_s, n_inv_s);
                     } else {
                         two_mask = two_masks[e1];
-                        perm_p = load_perm_head(tab1, rp1 + idx_base + ii);
-                        load_perm_row(tab1, rs1 + idx_base + ii, perm_s);
+                        perm_p = load_table_head<INV>(tab1, rp1 + idx_base + ii);
+                        load_table_row<INV>(tab1, rs1 + idx_base + ii, perm_s, inv_s);
                     }
                     const int j2 = t + 1 + VPF < N ? t + 1 + VPF : N - 1;
                     const uint32_t e2r = (uint32_t)schedule[3 * j2 + 0];
@@ -858,7 +895,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                         rocrand_words(spawn_seed, 2ull * (spawn_counter0 + (uint64_t)t) + 1ull, (uint64_t)(idx_base + ii), w4);
                         spawn_counter(s.board, w4[0], w4[1], thr);
                     } else {
-                        spawn_table(s.board, perm_s, two_mask, 1);
+                        if (INV) spawn_table_inv(s.board, perm_s, inv_s, two_mask);
+                        else spawn_table(s.board, perm_s, two_mask, 1);
                     }
                     if (LAZY) step_post_lazy(s); else step_post(s);
                     invalid = 0;
@@ -1275,19 +1313,21 @@ int64_t ml2048_rollout_scratch_ints(int64_t M, int32_t N) {
 }
 
 // schedule upload: 16 B per lane straight from device-accessible host memory
-__global__ __launch_bounds__(kBlock) void k_upload(uint4 *__restrict__ dst, const uint4 *__restrict__ src, int64_t n16) {
+__global__ __launch_bounds__(kBlock) void k_upload(uint4 *__restrict__ dst, const uint4 *__restrict__ src, int64_t n16,
+                                                   int64_t rows) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += (int64_t)gridDim.x * kBlock)
-        dst[i] = src[i];
+        upload_unit(dst, src, i, rows);
 }
 
-int ml2048_upload(void *stream, void *dst, const void *src_host, int64_t nbytes) {
+int ml2048_upload(void *stream, void *dst, const void *src_host, int64_t nbytes, int64_t n_table_rows) {
     if (!dst || !src_host || nbytes <= 0) return fail(ML2048_E_INVALID, "dst/src_host/nbytes");
+    if (n_table_rows < 0 || n_table_rows * 16 > nbytes) return fail(ML2048_E_INVALID, "n_table_rows=%lld", (long long)n_table_rows);
     if (((uintptr_t)dst | (uintptr_t)src_host) % 16) return fail(ML2048_E_ALIGN, "dst and src_host must be 16-byte aligned");
     const int64_t n16 = (nbytes + 15) / 16;
     int64_t blocks = cdiv(n16, kBlock);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(k_upload, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, (uint4 *)dst,
-                       (const uint4 *)src_host, n16);
+                       (const uint4 *)src_host, n16, n_table_rows);
     return check_launch("ml2048_upload");
 }
 
@@ -1347,8 +1387,10 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
                           int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0, uint8_t *actions_out,
                           uint64_t *digests_out, uint64_t *reset_flags, int32_t *last_reset, uint64_t spawn_seed,
                           uint64_t spawn_counter0, double two_prob, const ml2048_traj *traj_or_null,
-                          const void *up_src = nullptr, void *up_dst = nullptr, int64_t up_nbytes = 0) {
+                          const void *up_src = nullptr, void *up_dst = nullptr, int64_t up_nbytes = 0,
+                          int64_t up_rows = 0, bool inv_tables = false) {
     ml2048_traj traj = {};
+    if (up_rows < 0 || up_rows * 16 > up_nbytes) return fail(ML2048_E_INVALID, "next_table_rows=%lld", (long long)up_rows);
     if (up_src || up_dst || up_nbytes) {
         if (!up_src || !up_dst || up_nbytes <= 0) return fail(ML2048_E_INVALID, "next_src_host/next_dst/next_nbytes");
         if (((uintptr_t)up_src | (uintptr_t)up_dst) % 16) return fail(ML2048_E_ALIGN, "next_src_host and next_dst must be 16-byte aligned");
@@ -1371,16 +1413,19 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
     g_armed_timer = nullptr;
     hipEvent_t ev_start = timer ? timer->start : nullptr, ev_stop = timer ? timer->stop : nullptr;
     if (timer) timer->used = true;
-#define ML_LAUNCH2(K, F, X)                                                                                  \
-    hipExtLaunchKernelGGL((k_rollout<K, F, X>), grid, block, 0, s, ev_start, ev_stop, 0, *st, M, idx_base, N, perm_epochs, two_masks, \
+    if (inv_tables && (fast || extras)) return fail(ML2048_E_UNSUPPORTED, "expanded tables: plain table-mode rollouts only");
+#define ML_LAUNCH2(K, F, X, I)                                                                               \
+    hipExtLaunchKernelGGL((k_rollout<K, F, X, I>), grid, block, 0, s, ev_start, ev_stop, 0, *st, M, idx_base, N, perm_epochs, two_masks, \
                        schedule, n_epochs, masked, act_seed, act_counter0, actions_out, digests_out,         \
                        reset_flags, W,                                                                       \
-                       last_reset, spawn_seed, spawn_counter0, thr, traj, (const uint4 *)up_src, (uint4 *)up_dst, up_n16, up_blocks)
-#define ML_LAUNCH(K, F)          \
-    if (extras) {                \
-        ML_LAUNCH2(K, F, true);  \
-    } else {                     \
-        ML_LAUNCH2(K, F, false); \
+                       last_reset, spawn_seed, spawn_counter0, thr, traj, (const uint4 *)up_src, (uint4 *)up_dst, up_n16, up_blocks, up_rows)
+#define ML_LAUNCH(K, F)                 \
+    if (extras) {                       \
+        ML_LAUNCH2(K, F, true, false);  \
+    } else if (!F && inv_tables) {      \
+        ML_LAUNCH2(K, false, false, true); \
+    } else {                            \
+        ML_LAUNCH2(K, F, false, false); \
     }
 #define ML_KIND(F)                                                                   \
     switch (reward_kind) {                                                           \
@@ -1420,7 +1465,7 @@ int ml2048_rollout_chain(void *stream, int64_t M, int64_t idx_base, const ml2048
                          const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,
                          const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0,
                          uint64_t *reset_flags, int32_t *last_reset, const void *next_src_host, void *next_dst,
-                         int64_t next_nbytes) {
+                         int64_t next_nbytes, int64_t next_table_rows) {
     if (int rc = check_state(M, st)) return rc;
     if (N <= 0 || n_epochs <= 0) return fail(ML2048_E_INVALID, "N=%d n_epochs=%d must be positive", N, n_epochs);
     if (!perm_epochs || !two_masks || !schedule || !reset_flags || !last_reset)
@@ -1429,7 +1474,7 @@ int ml2048_rollout_chain(void *stream, int64_t M, int64_t idx_base, const ml2048
     if (idx_base < 0) return fail(ML2048_E_INVALID, "idx_base must be >= 0");
     return launch_rollout((hipStream_t)stream, false, M, idx_base, st, N, perm_epochs, two_masks, schedule, n_epochs, reward_kind,
                           masked, act_seed, act_counter0, nullptr, nullptr, reset_flags, last_reset, 0, 0, 0.0, nullptr,
-                          next_src_host, next_dst, next_nbytes);
+                          next_src_host, next_dst, next_nbytes, next_table_rows, /*inv_tables=*/true);
 }
 
 int ml2048_rollout_traj(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,

@@ -727,11 +727,24 @@ class VecGame:
             # small copy kernel in front of the rollout, or (host-async, plain rollouts) by the previous
             # rollout's own launch (ml2048_rollout_chain), which leaves nothing between two rollout kernels.
             asyn = self._schedule_mode == "host-async"
-            if asyn and self._la is not None and self._la["N"] != N:
-                self._close_sched_stream()  # the schedule taken ahead was for another length: drop it
+            plain = trajectory is None and not record_actions and not digests
+            # The pipelined form (host-async, plain rollouts) keeps EXPANDED tables on the device: every
+            # 16-byte permutation row followed by its inverse (what the upload kernels produce), for the
+            # one-shift-per-cell spawn of ml2048_rollout_chain.  A schedule taken ahead for another length,
+            # or in front of a rollout with optional outputs (which reads the plain layout), is dropped with
+            # the stream: the generator is re-synchronised to what was executed and the schedule redrawn.
+            if asyn and self._la is not None and (self._la["N"] != N or not plain):
+                self._close_sched_stream()
             cur = self._la if asyn else None
             self._la = None
             staged = []  # pinned slots read by this rollout's launches: released by its event
+            expand = asyn and plain
+
+            def dev_layout(E, o_sched, o_mask, nbytes):
+                grow = E * RAND_SIZE * 16 if expand else 0   # the inverse rows
+                return {"E": E, "o_sched": o_sched + grow, "o_mask": o_mask + grow, "nbytes": nbytes + grow,
+                        "rows": E * RAND_SIZE if expand else 0, "inv": expand}
+
             with self._dev_ctx():
                 if cur is None:
                     if asyn:
@@ -744,24 +757,27 @@ class VecGame:
                     pslot, (E, o_sched, o_mask, nbytes) = self._pack_pinned(sched, epochs, masks, N)
                     if asyn:
                         _lib.check(L.ml2048_sched_stream_release(self._sstream), "sched_stream_release")
+                    cur = dev_layout(E, o_sched, o_mask, nbytes)
                     self._sdev_i ^= 1
-                    dbuf = self._dev_sched_buf(self._sdev_i, nbytes)
-                    _lib.check(L.ml2048_upload(self._stream(join=False), dbuf.data_ptr(), pslot[0].data_ptr(), nbytes), "upload")
+                    dbuf = self._dev_sched_buf(self._sdev_i, cur["nbytes"])
+                    _lib.check(L.ml2048_upload(self._stream(join=False), dbuf.data_ptr(), pslot[0].data_ptr(), nbytes,
+                                               cur["rows"]), "upload")
                     staged.append(pslot)
-                    cur = {"N": N, "idx": self._sdev_i, "E": E, "o_sched": o_sched, "o_mask": o_mask, "after": after_state}
+                    cur.update({"N": N, "idx": self._sdev_i, "after": after_state})
                 E, o_sched, o_mask = cur["E"], cur["o_sched"], cur["o_mask"]
                 packed_dev = self._sdev[cur["idx"]]
                 chain = None
-                if asyn and trajectory is None and not record_actions and not digests:
-                    # take the next schedule now and let this launch upload it
+                if expand:
+                    # take the next schedule now and let this launch upload (and expand) it
                     sched, epochs, masks, after_next = self._next_schedule_async(N)
                     nslot, (E2, o_sched2, o_mask2, nbytes2) = self._pack_pinned(sched, epochs, masks, N)
                     _lib.check(L.ml2048_sched_stream_release(self._sstream), "sched_stream_release")
-                    ndev = self._dev_sched_buf(cur["idx"] ^ 1, nbytes2)
-                    chain = (nslot, ndev, nbytes2)
+                    nxt = dev_layout(E2, o_sched2, o_mask2, nbytes2)
+                    ndev = self._dev_sched_buf(cur["idx"] ^ 1, nxt["nbytes"])
+                    chain = (nslot, ndev, nbytes2, nxt["rows"])
                     staged.append(nslot)
-                    self._la = {"N": N, "idx": cur["idx"] ^ 1, "E": E2, "o_sched": o_sched2, "o_mask": o_mask2,
-                                "after": after_next}
+                    nxt.update({"N": N, "idx": cur["idx"] ^ 1, "after": after_next})
+                    self._la = nxt
             if asyn:
                 self._sstream_after = cur["after"]  # what _close_sched_stream re-synchronises the generator to
             perm_dev = packed_dev[:o_sched]
@@ -810,7 +826,7 @@ class VecGame:
                 _lib.check(L.ml2048_rollout_chain(
                     self._stream(join=False), M, self._idx_base, self._st(), N, perm_dev.data_ptr(), mask_dev.data_ptr(),
                     E, sched_dev.data_ptr(), self._reward_kind, int(masked), int(act_seed), int(act_counter),
-                    flags.data_ptr(), last.data_ptr(), chain[0][0].data_ptr(), chain[1].data_ptr(), chain[2]),
+                    flags.data_ptr(), last.data_ptr(), chain[0][0].data_ptr(), chain[1].data_ptr(), chain[2], chain[3]),
                     "rollout_chain")
             else:
                 _lib.check(L.ml2048_rollout(

@@ -86,6 +86,27 @@ int64_t h_move_forms_check(const uint8_t *boards, int64_t n) {
     return bad;
 }
 
+// spawn from the inverse permutation == spawn probing the permutation in order; returns differences
+int64_t h_spawn_forms_check(const uint8_t *boards, const uint8_t *perms, const uint32_t *two_masks, int64_t n) {
+    int64_t bad = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        Board a, b;
+        memcpy(a.r, boards + 16 * i, 16);
+        b = a;
+        uint32_t perm[4], inv[4];
+        memcpy(perm, perms + 16 * i, 16);
+        invert_perm_row(perm, inv);
+        for (int c = 0; c < 16; ++c) { // inv really is the inverse
+            const uint32_t pos = (inv[c >> 2] >> (8 * (c & 3))) & 0xFF;
+            if (((perm[pos >> 2] >> (8 * (pos & 3))) & 0xFF) != (uint32_t)c) ++bad;
+        }
+        spawn_table(a, perm, two_masks[i], 1);
+        spawn_table_inv(b, perm, inv, two_masks[i]);
+        if (memcmp(a.r, b.r, 16) != 0) ++bad;
+    }
+    return bad;
+}
+
 void h_transpose(const uint8_t *in, uint8_t *out) {
     Board b;
     memcpy(b.r, in, 16);

@@ -30,6 +30,8 @@ def H():
     L.h_move.argtypes = [vp, i64, vp, vp, vp, vp]
     L.h_valid.argtypes = [vp, i64, vp, vp, vp]
     L.h_transpose.argtypes = [vp, vp]
+    L.h_spawn_forms_check.argtypes = [vp, vp, vp, i64]
+    L.h_spawn_forms_check.restype = i64
     L.h_move_forms_check.argtypes = [vp, i64]
     L.h_move_forms_check.restype = i64
     L.h_lazy_mask_check.argtypes = [vp, i64]
@@ -136,6 +138,23 @@ def test_move_all_lines_at_once_equals_line_by_line(H):
     dense = rng.integers(1, 4, size=(100000, 16)).astype(np.uint8)
     allb = np.ascontiguousarray(np.concatenate([boards.reshape(-1, 16), cols.reshape(-1, 16), sparse, dense]))
     assert H.h_move_forms_check(_p(allb), allb.shape[0]) == 0
+
+
+def test_spawn_from_inverse_permutation_equals_probing_spawn(H):
+    """spawn_table_inv (one SDWA shift per cell + OR tree on the row's inverse permutation) places the
+    same tile as spawn_table for random boards (sparse, dense, full, empty) and random permutations."""
+    rng = np.random.default_rng(21)
+    n = 200000
+    boards = _random_boards(rng, n)
+    boards[: n // 4] = rng.integers(1, 6, size=(n // 4, 16))            # full boards: nothing to place
+    k = n // 4
+    holes = rng.integers(0, 16, size=k)
+    boards[k:2 * k] = rng.integers(1, 6, size=(k, 16))
+    boards[np.arange(k, 2 * k), holes] = 0                               # exactly one empty cell
+    boards[-1] = 0
+    perms = np.argsort(rng.random((n, 16)), axis=1).astype(np.uint8)
+    masks = rng.integers(0, 1 << 16, size=n).astype(np.uint32)
+    assert H.h_spawn_forms_check(_p(np.ascontiguousarray(boards)), _p(np.ascontiguousarray(perms)), _p(masks), n) == 0
 
 
 def test_lazy_mask_forms_agree_with_the_eager_mask(H):
