@@ -203,6 +203,14 @@ int ml2048_sched_stream_next(ml2048_sched_stream *s, const int32_t **schedule, c
                              int32_t *rand_step_after, const uint8_t **randperm_after,
                              const float **randfloat_after);
 int ml2048_sched_stream_release(ml2048_sched_stream *s);
+/* next() + release() with the schedule copied out in between, packed as the upload kernels expect:
+ * dst (typically pinned host memory) receives [n_epochs x 1024 x 16 tables | int32[n_steps][3] padded to
+ * 16 bytes | uint32[n_epochs] masks]; o_sched / o_mask / nbytes report the section offsets and the total
+ * (rounded up to 16).  randperm_after (16 KiB) / randfloat_after (1024 floats) may be NULL.  Returns
+ * ML2048_E_UNSUPPORTED without consuming anything when dst_capacity < *nbytes. */
+int ml2048_sched_stream_take(ml2048_sched_stream *s, void *dst, int64_t dst_capacity, int32_t *n_epochs,
+                             int64_t *o_sched, int64_t *o_mask, int64_t *nbytes, ml2048_pcg64 *rng_after,
+                             int32_t *rand_step_after, uint8_t *randperm_after, float *randfloat_after);
 void ml2048_sched_stream_destroy(ml2048_sched_stream *s);
 
 /* One table regeneration (`VecGame._reset_rand`, game_numba.py:589-591: permuted(axis=1) in place +

@@ -77,6 +77,9 @@ _SIGNATURES = {
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(Pcg64State),
                                            C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "ml2048_sched_stream_release": (C.c_int, [C.c_void_p]),
+    "ml2048_sched_stream_take": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                                           C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(Pcg64State),
+                                           C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),
     "ml2048_sched_stream_destroy": (None, [C.c_void_p]),
     "ml2048_hostrng_regen": (C.c_int, [C.POINTER(Pcg64State), C.c_void_p, C.c_void_p]),
     "ml2048_devrng_workspace_bytes": (C.c_int64, []),

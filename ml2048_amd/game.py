@@ -355,7 +355,7 @@ class VecGame:
             self._sdev[idx] = buf
         return buf
 
-    def _next_schedule_async(self, N: int):
+    def _open_sched_stream(self, N: int) -> None:
         L = self._L
         if self._sstream is not None and self._sstream_n != N:
             self._close_sched_stream()
@@ -371,24 +371,35 @@ class VecGame:
             if not self._sstream:
                 raise _lib.Ml2048Error("ml2048_sched_stream_create failed")
             self._sstream_n = N
-        p_s, p_e, p_m, p_rp, p_rf = (C.c_void_p() for _ in range(5))
+
+    def _take_schedule(self, N: int):
+        """The next schedule of the stream, packed straight into the next pinned buffer of the ring by ONE
+        native call (wait + three memcpy + release).  Returns (slot, (E, o_sched, o_mask, nbytes), after)."""
+        L = self._L
+        self._open_sched_stream(N)
+        i = self._spin_i
+        self._spin_i = (i + 1) % len(self._spin)
+        slot = self._spin[i]
+        if slot is not None and slot[1] is not None:
+            slot[1].synchronize()  # the launch that read this buffer (a ring length ago) has finished
+        if slot is None:
+            slot = [torch.empty((1 << 19,), dtype=torch.uint8, pin_memory=True), None]
+            self._spin[i] = slot
+        if len(slot) < 4:  # the generator / tables after this schedule, in buffers that live with the slot
+            slot += [np.empty((RAND_SIZE, 16), np.uint8), np.empty((RAND_SIZE,), np.float32)]
         ne, rs = C.c_int32(0), C.c_int32(0)
+        o_s, o_m, nb = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         after = _lib.Pcg64State()
-        _lib.check(L.ml2048_sched_stream_next(self._sstream, C.byref(p_s), C.byref(p_e), C.byref(p_m), C.byref(ne),
-                                              C.byref(after), C.byref(rs), C.byref(p_rp), C.byref(p_rf)),
-                   "sched_stream_next")
-        E = int(ne.value)
-
-        def view(ptr, nbytes, dtype):
-            return np.frombuffer((C.c_uint8 * nbytes).from_address(ptr.value), dtype=dtype)
-
-        sched = view(p_s, N * 12, np.int32).reshape(N, 3)
-        epochs = view(p_e, E * RAND_SIZE * 16, np.uint8).reshape(E, RAND_SIZE, 16)
-        masks = view(p_m, E * 4, np.uint32)
-        after_state = (after, rs.value, view(p_rp, RAND_SIZE * 16, np.uint8).reshape(RAND_SIZE, 16).copy(),
-                       view(p_rf, RAND_SIZE * 4, np.float32).copy())
-        # views into the stream's slot (valid until ml2048_sched_stream_release) + generator/tables after it
-        return sched, epochs, masks, after_state
+        while True:
+            rc = L.ml2048_sched_stream_take(self._sstream, slot[0].data_ptr(), slot[0].numel(), C.byref(ne), C.byref(o_s),
+                                            C.byref(o_m), C.byref(nb), C.byref(after), C.byref(rs),
+                                            slot[2].ctypes.data, slot[3].ctypes.data)
+            if rc == -3 and nb.value > slot[0].numel():  # unusually many epochs: a bigger pinned buffer
+                slot[0] = torch.empty((2 * nb.value,), dtype=torch.uint8, pin_memory=True)
+                continue
+            _lib.check(rc, "sched_stream_take")
+            break
+        return slot, (int(ne.value), int(o_s.value), int(o_m.value), int(nb.value)), (after, rs.value, slot[2], slot[3])
 
     def _pull_rng(self) -> None:
         """Make the host generator current again (before any host-side draw or inspection)."""
@@ -748,15 +759,13 @@ class VecGame:
             with self._dev_ctx():
                 if cur is None:
                     if asyn:
-                        sched, epochs, masks, after_state = self._next_schedule_async(N)
+                        pslot, (E, o_sched, o_mask, nbytes), after_state = self._take_schedule(N)
                     else:
                         sched, epochs, masks = self._next_schedule(N)
                         after_state = None
                         if prefetch_next:
                             self._start_prefetch(N)  # the NEXT schedule, on a worker thread (sync mode)
-                    pslot, (E, o_sched, o_mask, nbytes) = self._pack_pinned(sched, epochs, masks, N)
-                    if asyn:
-                        _lib.check(L.ml2048_sched_stream_release(self._sstream), "sched_stream_release")
+                        pslot, (E, o_sched, o_mask, nbytes) = self._pack_pinned(sched, epochs, masks, N)
                     cur = dev_layout(E, o_sched, o_mask, nbytes)
                     self._sdev_i ^= 1
                     dbuf = self._dev_sched_buf(self._sdev_i, cur["nbytes"])
@@ -769,9 +778,7 @@ class VecGame:
                 chain = None
                 if expand:
                     # take the next schedule now and let this launch upload (and expand) it
-                    sched, epochs, masks, after_next = self._next_schedule_async(N)
-                    nslot, (E2, o_sched2, o_mask2, nbytes2) = self._pack_pinned(sched, epochs, masks, N)
-                    _lib.check(L.ml2048_sched_stream_release(self._sstream), "sched_stream_release")
+                    nslot, (E2, o_sched2, o_mask2, nbytes2), after_next = self._take_schedule(N)
                     nxt = dev_layout(E2, o_sched2, o_mask2, nbytes2)
                     ndev = self._dev_sched_buf(cur["idx"] ^ 1, nxt["nbytes"])
                     chain = (nslot, ndev, nbytes2, nxt["rows"])
