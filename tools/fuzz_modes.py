@@ -21,17 +21,28 @@ while time.time() - t0 < budget:
     kind = kinds[rounds % 4]
     envs = {m: amd.VecGame(M, kind, schedule=m) for m in ("host", "host-async", "device")}
     step_env = amd.VecGame(M, kind)
-    pol = amd.RandomPolicy(seed=5, masked=True)
+    masked = bool(rounds % 3 != 1)  # unmasked rounds run the lazy-mask loop and the inverse-permutation spawn
+    pol = amd.RandomPolicy(seed=5, masked=masked)
+    last_n = 128
     seed = int(rng.integers(0, 2**31))
     for e in list(envs.values()) + [step_env]:
         e.reset(seed)
     counter = 0
     for _ in range(int(rng.integers(5, 25))):
         op = rng.integers(0, 10)
-        if op < 6:  # fused rollout of a random length
-            n = int(rng.choice([1, 2, 7, 33, 64, 128, 200]))
-            for e in envs.values():
-                e.rollout(n, masked=True, act_seed=5, act_counter=counter)
+        if op < 6:  # fused rollout: often the same length again (chained upload of the schedule taken ahead),
+            # with the id scan inline or deferred, sometimes with per-step digests (drops the look-ahead)
+            n = last_n if rng.random() < 0.5 else int(rng.choice([1, 2, 7, 33, 64, 128, 200]))
+            last_n = n
+            fin = "deferred" if rng.random() < 0.5 else True
+            dig = rng.random() < 0.15
+            outs = {}
+            for m, e in envs.items():
+                outs[m] = e.rollout(n, masked=masked, act_seed=5, act_counter=counter, finish_ids=fin, digests=dig)
+            if dig:
+                d0 = outs["host"]["digests"].cpu().numpy()
+                for m in outs:
+                    assert np.array_equal(outs[m]["digests"].cpu().numpy(), d0), (rounds, ops, m, "digests")
             for _ in range(n):
                 step_env.prepare_torch()
                 pol.counter = counter
