@@ -350,6 +350,23 @@ int ml2048_rollout_finish_ids(void *stream, int64_t M, const ml2048_state *st, i
                               int32_t *game_count, int32_t *step_resets, int32_t *scratch);
 
 /*
+ * Episode statistics of the FIRST `rounds` games - the evaluation loop of eval_perf.py:64-102 with
+ * ReplayRecorder (src/ml2048/replay.py:110-232) as its collector, on device.  Call once after every
+ * ml2048_step (per-step API).  Per slot, age[] counts the steps its current game has lived (what the
+ * recorder's buffer.steps counts, replay.py:167: every step, valid move or not); a new id in the slot
+ * restarts the count; in the step that terminates a game with id < rounds the kernel adds
+ * (1, age, final score) to entry [max tile exponent] of count / step_sum / score_sum (eval_perf.py:88-99;
+ * scores are integer-valued, so the integer sum equals the reference's float sum).
+ *   age, seen_id    device int32[M], 16-byte aligned (as st->id; st->terminated 4-byte aligned); initialise age
+ *                   to 0 and seen_id to INT32_MIN (or any id never used)
+ *   count, step_sum, score_sum   device uint64[18], zero-initialised by the caller; index = max exponent
+ * The evaluation is complete when sum(count) == rounds ("the first N games, not the first N terminated
+ * games", README.md:112-118).
+ */
+int ml2048_episode_stats(void *stream, int64_t M, const ml2048_state *st, int32_t *age, int32_t *seen_id,
+                         int32_t rounds, uint64_t *count, uint64_t *step_sum, uint64_t *score_sum);
+
+/*
  * ---- rollout consumers (SURVEY 8f "next" rows) ------------------------------------------------
  *
  * One transition slice straight into the trainer's `[use, step, game]` replay buffers with the

@@ -19,6 +19,7 @@ from .game import (  # noqa: F401
     reward_fn_normal,
     reward_fn_rank,
 )
+from .evalstats import EpisodeStats, evaluate  # noqa: F401
 from .hostrng import HostRng  # noqa: F401
 from .policy import Policy, RandomPolicy  # noqa: F401
 from .runner import EventEmitter, RunnerStats, VecRunner  # noqa: F401

@@ -1075,6 +1075,78 @@ __global__ __launch_bounds__(kBlock) void k_ids_assign(ml2048_state st, int64_t 
     st.id[i] = gc0 + step_base[t] + rank;
 }
 
+// ---- episode statistics of the first `rounds` games (eval_perf.py:64-102 + replay.py:110-232) ------------
+// The reference evaluates a policy by recording every game from its deal to its termination
+// (ReplayRecorder: buffer.steps += 1 per on_stepped call, replay.py:167; the last appended score is the
+// final score, :186-192) and, for the games whose id < rounds, adding (1, steps, score) to the entry of their
+// max tile (eval_perf.py:88-99) - "the first N games, not the first N terminated games" (README.md:112-118).
+// Here that is one pass after every step: `age` counts the steps a slot's current game has lived (a new id in
+// the slot restarts it), and a game is folded into the table in the step that terminates it.
+constexpr int kStatsBlock = 1024;
+__global__ __launch_bounds__(kStatsBlock) void k_episode_stats(ml2048_state st, int64_t M, int32_t *__restrict__ age,
+                                                          int32_t *__restrict__ seen_id, int32_t rounds,
+                                                          unsigned long long *__restrict__ count,
+                                                          unsigned long long *__restrict__ step_sum,
+                                                          unsigned long long *__restrict__ score_sum) {
+    // Terminations are rare per board but land on a handful of table entries: they are accumulated per
+    // workgroup in LDS over a grid-stride loop and flushed with at most 54 global atomics per workgroup
+    // (one global atomic per terminated board serialised on ~10 addresses: 186 us at 4 M boards; 2048 small
+    // workgroups still 52 us; 512 workgroups of 1024 threads: see profiles/).
+    __shared__ unsigned long long acc[3][18];
+    if (threadIdx.x < 54) acc[threadIdx.x / 18][threadIdx.x % 18] = 0ull;
+    __syncthreads();
+    // four boards per lane: 16-byte accesses to id / age / seen_id, 4 bytes of flags
+    auto one = [&](int64_t i, int32_t id, int32_t a, int32_t &seen, uint32_t term) -> int32_t {
+        if (id != seen) { // a new game was dealt into this slot
+            a = 0;
+            seen = id;
+        }
+        if (a >= 0) { // a < 0: already folded in, waiting for its re-deal
+            a += 1;
+            if (term) {
+                if (id >= 0 && id < rounds) {
+                    const Board b = load_board(st.board, i);
+                    const uint32_t mc = max_cell(b);
+                    atomicAdd(&acc[0][mc], 1ull);
+                    atomicAdd(&acc[1][mc], (unsigned long long)a);
+                    // scores are integer-valued float32 (sums of tile values), so the integer sum is exact
+                    atomicAdd(&acc[2][mc], (unsigned long long)(long long)st.score[i]);
+                }
+                a = -1;
+            }
+        }
+        return a;
+    };
+    const int64_t quads = M / 4;
+    for (int64_t q = (int64_t)blockIdx.x * kStatsBlock + threadIdx.x; q < quads; q += (int64_t)gridDim.x * kStatsBlock) {
+        const int4 id4 = reinterpret_cast<const int4 *>(st.id)[q];
+        int4 a4 = reinterpret_cast<const int4 *>(age)[q];
+        int4 s4 = reinterpret_cast<const int4 *>(seen_id)[q];
+        const uint32_t t4 = reinterpret_cast<const uint32_t *>(st.terminated)[q];
+        const int4 s4_in = s4;
+        a4.x = one(4 * q + 0, id4.x, a4.x, s4.x, t4 & 0xFFu);
+        a4.y = one(4 * q + 1, id4.y, a4.y, s4.y, (t4 >> 8) & 0xFFu);
+        a4.z = one(4 * q + 2, id4.z, a4.z, s4.z, (t4 >> 16) & 0xFFu);
+        a4.w = one(4 * q + 3, id4.w, a4.w, s4.w, t4 >> 24);
+        reinterpret_cast<int4 *>(age)[q] = a4;
+        if (s4.x != s4_in.x || s4.y != s4_in.y || s4.z != s4_in.z || s4.w != s4_in.w) reinterpret_cast<int4 *>(seen_id)[q] = s4;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)(M - 4 * quads)) { // the last M % 4 boards
+        const int64_t i = 4 * quads + threadIdx.x;
+        int32_t seen = seen_id[i];
+        age[i] = one(i, st.id[i], age[i], seen, st.terminated[i]);
+        seen_id[i] = seen;
+    }
+    __syncthreads();
+    if (threadIdx.x < 54) {
+        const unsigned long long v = acc[threadIdx.x / 18][threadIdx.x % 18];
+        if (v) {
+            unsigned long long *dst = threadIdx.x < 18 ? count : (threadIdx.x < 36 ? step_sum : score_sum);
+            atomicAdd(dst + threadIdx.x % 18, v);
+        }
+    }
+}
+
 // ---- transition record (run_train3.py:125-155) -------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_record(ml2048_state st, int64_t M, const uint8_t *__restrict__ actions,
                                                    const float *__restrict__ logp, int8_t *__restrict__ o_state,
@@ -1526,6 +1598,22 @@ int ml2048_rollout_finish_ids(void *stream, int64_t M, const ml2048_state *st, i
                            game_count, (int32_t)snap);
     }
     return check_launch("ml2048_rollout_finish_ids");
+}
+
+int ml2048_episode_stats(void *stream, int64_t M, const ml2048_state *st, int32_t *age, int32_t *seen_id,
+                         int32_t rounds, uint64_t *count, uint64_t *step_sum, uint64_t *score_sum) {
+    if (int rc = check_state(M, st)) return rc;
+    if (!age || !seen_id || !count || !step_sum || !score_sum) return fail(ML2048_E_INVALID, "age/seen_id/count/step_sum/score_sum is NULL");
+    if (rounds < 0) return fail(ML2048_E_INVALID, "rounds=%d", rounds);
+    if (((uintptr_t)age | (uintptr_t)seen_id | (uintptr_t)st->id) % 16 || (uintptr_t)st->terminated % 4)
+        return fail(ML2048_E_ALIGN, "age, seen_id and st->id must be 16-byte aligned, st->terminated 4-byte aligned");
+    int64_t blocks = cdiv(cdiv(M, 4), kStatsBlock); // grid-stride over 4-board units: big workgroups keep the flushes rare
+    if (blocks < 1) blocks = 1;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(k_episode_stats, dim3((unsigned)blocks), dim3(kStatsBlock), 0, (hipStream_t)stream, *st, M, age,
+                       seen_id, rounds, (unsigned long long *)count, (unsigned long long *)step_sum,
+                       (unsigned long long *)score_sum);
+    return check_launch("ml2048_episode_stats");
 }
 
 int ml2048_record_transition(void *stream, int64_t M, const ml2048_state *st, const uint8_t *actions,

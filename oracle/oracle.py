@@ -325,3 +325,46 @@ class OracleVecGame:
 
     def digest(self, with_id: bool = True) -> int:
         return int(lib().orc_digest(_p(self._data), self._size, self._idx_base, int(with_id)))
+
+
+def eval_first_games(game: "OracleVecGame", next_actions, rounds: int, max_steps: int = 1_000_000):
+    """TEST INFRASTRUCTURE: the reference's evaluation loop restated in plain Python - eval_perf.py:64-102
+    driving ReplayRecorder's bookkeeping (src/ml2048/replay.py:133-200; thresholds = batch size as
+    eval_perf.py:69 sets them): a game is recorded from the prepare() that deals it; buffer.steps += 1 per
+    on_stepped (:167); on termination its (max tile, steps, final score) is queued (:178-200); the consumer adds
+    games with id < rounds to stats[2**maxcell] and, on the first id >= rounds, stops new recordings (:84-90).
+    `next_actions(game)` returns the action vector of the next step.  Returns ({tile: [count, step_sum,
+    score_sum]}, steps played)."""
+    recording = {}            # game id -> [slot, steps]   (dict order = recording order, as in the reference)
+    recording_threshold = game._size
+    stats = {}
+    remaining, steps = rounds, 0
+    while remaining > 0:
+        if steps >= max_steps:
+            raise RuntimeError("evaluation did not finish")
+        (new_indices,) = game.prepare()
+        free = min(new_indices.size, recording_threshold - len(recording))   # replay.py:140-143
+        for i in range(max(0, free)):
+            slot = int(new_indices[i])
+            recording[int(game._data[slot]["id"])] = [slot, 0]
+        result = game.step(next_actions(game))
+        steps += 1
+        ready = []
+        for gid, rec in recording.items():                                     # replay.py:165-192
+            rec[1] += 1
+            if result["terminated"][rec[0]]:
+                ready.append((gid, rec[1], int(result["state"][rec[0]].max()), float(result["score"][rec[0]])))
+        for gid, _, _, _ in ready:
+            recording.pop(gid)
+        for gid, nsteps, maxcell, score in ready:                              # eval_perf.py:84-99
+            if remaining <= 0:
+                break
+            if gid >= rounds:
+                recording_threshold = 0
+                continue
+            remaining -= 1
+            e = stats.setdefault(2 ** maxcell, [0, 0, 0.0])
+            e[0] += 1
+            e[1] += nsteps
+            e[2] += score
+    return stats, steps

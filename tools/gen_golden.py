@@ -19,6 +19,8 @@ Outputs (all small, committed):
   tests/golden/rollout_long.npz   M=256, N=1200, unmasked actions (termination/reset/ids/stale)
   tests/golden/rollout_rewards.npz  M=128, N=300 for each of the 4 reward functions
   tests/golden/reward_triples.npz random (state, prev, merged) -> 4 reward values
+  tests/golden/eval_first_games.npz  eval_perf.py's loop (ReplayRecorder as collector) on M=64, rounds=150:
+                                  the action sequence and the resulting per-max-tile table
   tests/golden/known_answer.json  the playground.ipynb cell-11 vector, re-derived here
   tests/golden/MANIFEST.json      sha256 of every file + numpy version used
 
@@ -268,6 +270,58 @@ def gen_rollouts(gn, out):
     return info
 
 
+def gen_eval(gn, out):
+    """The reference's evaluation loop (eval_perf.py:64-102) with the reference's own ReplayRecorder
+    (src/ml2048/replay.py:110-232) and VecGame, driven by pre-drawn actions instead of a policy network:
+    masked-uniform for the first configuration (no invalid moves, as a trained policy), unmasked for the
+    second (invalid moves make the recorder's `steps` differ from the record's `step` field)."""
+    import torch  # the recorder takes the action vector as a tensor (replay.py:160)
+    import ml2048.replay as rp
+
+    payload, info = {}, {}
+    for tag, M, rounds, seed, mode in (("masked", 64, 150, 31, "masked"), ("unmasked", 48, 120, 32, "unmasked")):
+        game = gn.VecGame(M)
+        game.reset(seed)
+        recorder = rp.ReplayRecorder(M, M)
+        arng = np.random.default_rng(900 + seed)
+        stats = {}
+        remaining, steps = rounds, 0
+        actions_all = []
+        while remaining > 0:
+            (new_indices,) = game.prepare()                      # VecRunner.step_once, runner.py:80-109
+            recorder.on_prepared(game, new_indices)
+            _, valid = game.observations()
+            a = _masked_uniform_actions(arng, valid) if mode == "masked" else arng.integers(0, 4, size=M)
+            actions_all.append(np.asarray(a, np.uint8))
+            result = game.step(a)
+            recorder.on_stepped(game, result, torch.from_numpy(np.asarray(a)), None)
+            steps += 1
+            while recorder.ready_buffers and remaining > 0:      # eval_perf.py:84-99
+                buffer = recorder.ready_buffers.popleft()
+                if buffer.id >= rounds:
+                    recorder.recording_threshold = 0
+                    continue
+                remaining -= 1
+                e = stats.setdefault(2 ** buffer.maxcell, [0, 0, 0.0])
+                e[0] += 1
+                e[1] += buffer.steps
+                e[2] += buffer.score
+        keys = sorted(stats)
+        payload[f"{tag}_M"] = np.int64(M)
+        payload[f"{tag}_rounds"] = np.int64(rounds)
+        payload[f"{tag}_seed"] = np.int64(seed)
+        payload[f"{tag}_actions"] = np.stack(actions_all)
+        payload[f"{tag}_tiles"] = np.array(keys, np.int64)
+        payload[f"{tag}_count"] = np.array([stats[k][0] for k in keys], np.int64)
+        payload[f"{tag}_step_sum"] = np.array([stats[k][1] for k in keys], np.int64)
+        payload[f"{tag}_score_sum"] = np.array([stats[k][2] for k in keys], np.float64)
+        info[f"eval_first_games.{tag}.steps"] = steps
+        info[f"eval_first_games.{tag}.table"] = {str(k): stats[k] for k in keys}
+        print(f"  eval {tag}: {steps} steps, table {info[f'eval_first_games.{tag}.table']}", flush=True)
+    np.savez_compressed(os.path.join(out, "eval_first_games.npz"), **payload)
+    return info
+
+
 def gen_reward_triples(gn, out):
     rng = np.random.default_rng(31337)
     T = 4096
@@ -322,6 +376,7 @@ def gen_known_answer(gn, raw, out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    ap.add_argument("--only", default=None, help="regenerate one group only (e.g. eval); the others keep their MANIFEST entries")
     args = ap.parse_args()
     out = os.path.abspath(args.out)
     os.makedirs(out, exist_ok=True)
@@ -334,13 +389,19 @@ def main():
         setattr(gn, f"reward_fn_{n}", _as_i64(fn))
 
     info = {"numpy": np.__version__, "generated_by": "tools/gen_golden.py"}
+    if args.only and os.path.exists(os.path.join(out, "MANIFEST.json")):
+        with open(os.path.join(out, "MANIFEST.json")) as f:
+            info.update({k: v for k, v in json.load(f).items() if k != "files"})
     for name, fn in (
         ("known_answer", lambda: gen_known_answer(gn, raw, out)),
         ("lines", lambda: gen_lines(gn, out)),
         ("rng", lambda: gen_rng(gn, out)),
         ("reward_triples", lambda: gen_reward_triples(gn, out)),
         ("rollouts", lambda: gen_rollouts(gn, out)),
+        ("eval", lambda: gen_eval(gn, out)),
     ):
+        if args.only and name != args.only:
+            continue
         t0 = time.time()
         info.update(fn())
         print(f"{name}: {time.time()-t0:.1f}s", flush=True)
