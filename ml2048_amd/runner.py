@@ -76,6 +76,16 @@ class VecRunner:
         return result
 
     def step_many(self, policy: Policy, count: int) -> None:
+        """runner.py:111-117.  With a RandomPolicy and no listeners nothing observes the individual steps, so
+        the `count` prepare/sample/step triples run as ONE fused launch (`VecGame.rollout`): same sampler
+        stream (seed, call counter), same final state, ids and generator state as the loop
+        (`tests/test_gpu_parity.py::test_runner_step_many_fuses_random_rollouts`)."""
+        if (count > 0 and isinstance(policy, RandomPolicy) and policy.idx_base == self.env._idx_base
+                and not self._emitter.has_listeners(self.EVENT_PREPARED)
+                and not self._emitter.has_listeners(self.EVENT_STEPPED)):
+            self.env.rollout(count, masked=policy.masked, act_seed=policy.seed, act_counter=policy.counter)
+            policy.counter += count
+            return
         for _ in range(count):
             self.step_once(policy)
 

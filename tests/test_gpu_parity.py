@@ -423,6 +423,29 @@ def test_device_schedule_rollouts_equal_host_schedule_rollouts(amd):
     assert a.digest() == b.digest()
 
 
+def test_runner_step_many_fuses_random_rollouts(amd):
+    """VecRunner.step_many(RandomPolicy, n) without listeners is one fused launch; with a listener it is the
+    reference's loop.  Both leave the same records, ids, game counter, generator state and policy counter."""
+    M = 3000
+    a, b = amd.VecGame(M, "rank"), amd.VecGame(M, "rank")
+    a.reset(11)
+    b.reset(11)
+    pa, pb = amd.RandomPolicy(seed=9, masked=False), amd.RandomPolicy(seed=9, masked=False)
+    ra, rb = amd.VecRunner(a, M), amd.VecRunner(b, M)
+    seen = []
+    rb.add_callback(amd.VecRunner.EVENT_STEPPED, lambda env, result, actions, lp: seen.append(1))
+    for n in (40, 1, 128):
+        ra.step_many(pa, n)   # fused
+        rb.step_many(pb, n)   # per step (a listener is registered)
+        assert a._data.tobytes() == b._data.tobytes(), n
+        assert a._game_count == b._game_count and a._rand_step == b._rand_step
+        assert pa.counter == pb.counter
+    assert len(seen) == 169
+    ra.step_once(pa)
+    rb.step_once(pb)
+    assert a.digest() == b.digest()
+
+
 def test_deferred_id_scan_equals_inline(amd):
     """rollout(finish_ids="deferred") (id scan on a side stream, overlapped with the next rollout) leaves
     the same ids, game counter, per-step re-deal counts and records as the inline scan - also when the
