@@ -73,6 +73,19 @@ class Encoder(nn.Module):
         x = torch.cat((a, b, c), dim=2).flatten(1)
         return F.leaky_relu(F.linear(x, self.fold.weight.flatten(1), self.fold.bias))
 
+    @torch.no_grad()
+    def forward_boards(self, board: torch.Tensor) -> torch.Tensor:
+        """Inference straight from (N,16) boards: the three depthwise convolutions + leaky_relu come from ONE
+        HIP gather kernel (ml2048_encoder_front; the one-hot is never built), the dense part
+        stays on hipBLASLt.  Same function as forward(onehot) up to float rounding."""
+        n = board.shape[0]
+        a, b, c = train_ops.encoder_front(board, self.dw_full, self.dw_rows, self.dw_cols)
+        a = F.leaky_relu(F.linear(a, self.pw_full.weight.flatten(1), self.pw_full.bias)).reshape(n, self.ch, 4)
+        b = F.leaky_relu(torch.einsum("nkr,ok->nor", b, self.pw_rows.weight.flatten(1)) + self.pw_rows.bias[:, None])
+        c = F.leaky_relu(torch.einsum("nkw,ok->now", c, self.pw_cols.weight.flatten(1)) + self.pw_cols.bias[:, None])
+        x = torch.cat((a, b, c), dim=2).flatten(1)
+        return F.leaky_relu(F.linear(x, self.fold.weight.flatten(1), self.fold.bias))
+
 
 def _mlp(i, h1, h2, o, out_gain):
     layers = [nn.Linear(i, h1), nn.ReLU(), nn.Linear(h1, h2), nn.ReLU(), nn.Linear(h2, o)]
@@ -104,14 +117,23 @@ class ActorCritic(nn.Module, amd.Policy):
         return self.critic(self.encoder(onehot)).squeeze(-1).float()
 
     @torch.no_grad()
-    def value_of_states(self, state_i8, chunk=16384):
-        """Critic over a long list of (N,16) int8 states, in chunks (keeps conv launches modest)."""
-        out = [self.value(onehot_of(state_i8[i:i + chunk])) for i in range(0, state_i8.shape[0], chunk)]
+    def value_of_states(self, state_i8, chunk=65536, fused=True):
+        """Critic over a long list of (N,16) int8 states, in chunks."""
+        if fused:
+            out = [self.critic(self.encoder.forward_boards(state_i8[i:i + chunk])).squeeze(-1).float()
+                   for i in range(0, state_i8.shape[0], chunk)]
+        else:
+            out = [self.value(onehot_of(state_i8[i:i + 16384])) for i in range(0, state_i8.shape[0], 16384)]
         return torch.cat(out)
 
     @torch.no_grad()
-    def act(self, onehot, valid_bool):
-        z = self.logits(onehot)
+    def act(self, onehot, valid_bool, board=None):
+        """Sample actions; with `board` ((N,16) uint8) the encoder runs on the fused front end."""
+        if board is not None:
+            z = self.actor(self.encoder.forward_boards(board))
+            z = z - z.max(dim=-1, keepdim=True).values
+        else:
+            z = self.logits(onehot)
         z = torch.where(valid_bool, z, torch.finfo(z.dtype).min)
         dist = torch.distributions.Categorical(logits=z)
         a = torch.multinomial(dist.probs, 1, True).squeeze(-1)
@@ -187,6 +209,8 @@ def main():
     ap.add_argument("--use", type=int, default=2)
     ap.add_argument("--seed", type=int, default=20241008)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--fused-front", type=int, default=1,
+                    help="no-grad encoder passes (rollout policy, GAE critic passes) through ml2048_encoder_front")
     args = ap.parse_args()
     torch.manual_seed(args.seed)
     dev = torch.device("cuda:0")
@@ -214,9 +238,10 @@ def main():
         for si in range(S):  # VecRunner.step_once, runner.py:74-109, with everything on device
             te = time.perf_counter()
             env.prepare_torch()
-            env.onehot(out=obs)
+            if not args.fused_front:
+                env.onehot(out=obs)
             t_env += time.perf_counter() - te
-            a, lp = net_eval.act(obs, env.valid_actions.bool())
+            a, lp = net_eval.act(obs, env.valid_actions.bool(), board=env.board if args.fused_front else None)
             te = time.perf_counter()
             res = env.step_torch(a.to(torch.uint8))
             train_ops.record_transition(env, a, lp, buffers, ui, si)
@@ -227,8 +252,8 @@ def main():
         n_use = min(epoch + 1, U)
         view = {k: v[:n_use] for k, v in buffers.items()}
         # gae.py:39-48: two critic passes, then the HIP scan
-        v0 = net_eval.value_of_states(view["state"].reshape(-1, 16)).reshape(n_use, S, M)
-        v1 = net_eval.value_of_states(view["next_state"].reshape(-1, 16)).reshape(n_use, S, M)
+        v0 = net_eval.value_of_states(view["state"].reshape(-1, 16), fused=bool(args.fused_front)).reshape(n_use, S, M)
+        v1 = net_eval.value_of_states(view["next_state"].reshape(-1, 16), fused=bool(args.fused_front)).reshape(n_use, S, M)
         train_ops.gae(v0, v1, view["reward"], view["terminated"], gamma=p["gamma"], lambda_=p["lambda"],
                       adv=view["adv"] if view["adv"].is_contiguous() else None)
         data = {k: v.flatten(0, 2) for k, v in view.items()}

@@ -350,6 +350,25 @@ int ml2048_rollout_finish_ids(void *stream, int64_t M, const ml2048_state *st, i
                               int32_t *game_count, int32_t *step_resets, int32_t *scratch);
 
 /*
+ * Front end of the reference's CNN encoder (CNNEncoder.forward, src/ml2048/policy/_network.py:84-119),
+ * leaky_relu of the three depthwise convolutions over the one-hot board - whole board
+ * (:30-35, :98-100), rows (:42-47, :108-110), columns (:54-59, :114-116) - computed as weight gathers
+ * straight from the 16-byte board; the one-hot is never materialised.  multiplier = 16, 16 classes:
+ *   board      device uint8[N][16] exponents (a cell >= 16 has no class and contributes nothing; the
+ *              reference's F.one_hot raises for it), 16-byte aligned
+ *   w_full     device float[256][16]  = _depthwise_full.weight (256,1,16);   b_full float[256]
+ *   w_rows     device float[256][4]   = _depthwise_hori.weight (256,1,1,4);  b_rows float[256]
+ *   w_cols     device float[256][4]   = _depthwise_vert.weight (256,1,4,1);  b_cols float[256]
+ *   out_full   device float[N][256]   = leaky_relu(_depthwise_full(x))  flattened     (16-byte aligned)
+ *   out_rows   device float[N][256][4] = leaky_relu(_depthwise_hori(board)) (N,256,4,1)
+ *   out_cols   device float[N][256][4] = leaky_relu(_depthwise_vert(board)) (N,256,1,4)
+ * Sums run over cells in ascending order; equal to torch's convolutions to rounding, not bit for bit.
+ */
+int ml2048_encoder_front(void *stream, int64_t N, const uint8_t *board, const float *w_full, const float *b_full,
+                         const float *w_rows, const float *b_rows, const float *w_cols, const float *b_cols,
+                         float negative_slope, float *out_full, float *out_rows, float *out_cols);
+
+/*
  * Episode statistics of the FIRST `rounds` games - the evaluation loop of eval_perf.py:64-102 with
  * ReplayRecorder (src/ml2048/replay.py:110-232) as its collector, on device.  Call once after every
  * ml2048_step (per-step API).  Per slot, age[] counts the steps its current game has lived (what the

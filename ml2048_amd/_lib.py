@@ -92,6 +92,8 @@ _SIGNATURES = {
     "ml2048_timer_arm": (C.c_int, [C.c_void_p]),
     "ml2048_timer_elapsed_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "ml2048_timer_destroy": (None, [C.c_void_p]),
+    "ml2048_encoder_front": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ml2048_episode_stats": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(State), C.c_void_p, C.c_void_p, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "ml2048_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),

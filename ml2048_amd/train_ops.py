@@ -81,3 +81,38 @@ def gae(v0: torch.Tensor, v1: torch.Tensor, reward: torch.Tensor, terminated: to
         _lib.check(L.ml2048_gae(stream, U, S, G, v0.data_ptr(), v1.data_ptr(), reward.data_ptr(), term.data_ptr(),
                                 float(gamma), float(lambda_), adv.data_ptr(), _ptr(delta)), "gae")
     return (adv, delta) if want_delta else adv
+
+
+def encoder_front(board: torch.Tensor, dw_full, dw_rows, dw_cols, *, negative_slope: float = 0.01, out=None):
+    """leaky_relu of the reference encoder's three depthwise convolutions (`CNNEncoder.forward`,
+    src/ml2048/policy/_network.py:98-116) computed straight from the (N,16) board - the one-hot is never
+    materialised.  `dw_full` / `dw_rows` / `dw_cols` are the reference's modules
+    (`_depthwise_full` Conv1d(16,256,16,groups=16), `_depthwise_hori` Conv2d (1,4), `_depthwise_vert` Conv2d (4,1))
+    or anything with `.weight` / `.bias` of those shapes.  Inference only (no autograd through the kernel).
+
+    Returns (full (N,256), rows (N,256,4), cols (N,256,4)) float32: the inputs of `_pointwise_full`,
+    `_pointwise_hori` (as (N,256,4,1)) and `_pointwise_vert` (as (N,256,1,4))."""
+    assert board.is_cuda and board.ndim == 2 and board.shape[1] == 16, board.shape
+    b = board if board.dtype == torch.uint8 else board.to(torch.uint8)
+    b = b.contiguous()
+    N, dev = b.shape[0], b.device
+
+    def flat(t, shape):
+        t = t.detach().to(device=dev, dtype=torch.float32).reshape(shape).contiguous()
+        return t
+
+    wf, bf = flat(dw_full.weight, (256, 16)), flat(dw_full.bias, (256,))
+    wr, br = flat(dw_rows.weight, (256, 4)), flat(dw_rows.bias, (256,))
+    wc, bc = flat(dw_cols.weight, (256, 4)), flat(dw_cols.bias, (256,))
+    if out is None:
+        out = (torch.empty((N, 256), dtype=torch.float32, device=dev),
+               torch.empty((N, 256, 4), dtype=torch.float32, device=dev),
+               torch.empty((N, 256, 4), dtype=torch.float32, device=dev))
+    L = _lib.load()
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(idx):
+        _lib.check(L.ml2048_encoder_front(torch.cuda.current_stream(dev).cuda_stream, N, b.data_ptr(), wf.data_ptr(),
+                                          bf.data_ptr(), wr.data_ptr(), br.data_ptr(), wc.data_ptr(), bc.data_ptr(),
+                                          float(negative_slope), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr()),
+                   "encoder_front")
+    return out
