@@ -32,11 +32,16 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kCh = 256; // 16 classes x multiplier 16
 
-__device__ __forceinline__ uint32_t eq_flags(uint32_t word, uint32_t kkkk) { // 0x80 in every byte equal to k (bytes < 0x80)
-    return ~((word ^ kkkk) + 0x7F7F7F7Fu) & 0x80808080u;
+// 0x01 in every byte of `word` equal to the class byte (bytes < 0x80); v_cvt_f32_ubyteN then turns one
+// such byte into the float 0.0 / 1.0 that multiplies a weight: acc = fma(flag, w, acc) is exactly
+// "acc += w if the cell has this class" (1.0 * w is exact), in two instructions per term and without a
+// compare / select pair per term
+__device__ __forceinline__ uint32_t eq_bytes(uint32_t word, uint32_t kkkk) {
+    return (~((word ^ kkkk) + 0x7F7F7F7Fu) & 0x80808080u) >> 7;
 }
+__device__ __forceinline__ float byte_f32(uint32_t x, int j) { return (float)((x >> (8 * j)) & 0xFFu); } // v_cvt_f32_ubyteN
 
-__device__ __forceinline__ float lrelu(float x, float slope) { return x >= 0.0f ? x : x * slope; }
+__device__ __forceinline__ float lrelu(float x, float slope) { return fmaxf(x, x * slope); } // 0 <= slope <= 1
 
 __global__ __launch_bounds__(kThreads) void k_encoder_front(const uint4 *__restrict__ board, int64_t N,
                                                             const float *__restrict__ w_full, const float *__restrict__ b_full,
@@ -73,13 +78,16 @@ __global__ __launch_bounds__(kThreads) void k_encoder_front(const uint4 *__restr
             float4 acc = make_float4(s_bf[c0], s_bf[c0 + 1], s_bf[c0 + 2], s_bf[c0 + 3]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint32_t eq = eq_flags(r[q], kkkk);
+                const uint32_t eq = eq_bytes(r[q], kkkk);
 #pragma unroll
-                for (int w = 0; w < 4; ++w)
-                    if (eq & (0x80u << (8 * w))) {
-                        const float4 v = *reinterpret_cast<const float4 *>(&s_full[4 * q + w][c0]);
-                        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-                    }
+                for (int w = 0; w < 4; ++w) { // cells in ascending order
+                    const float f = byte_f32(eq, w);
+                    const float4 v = *reinterpret_cast<const float4 *>(&s_full[4 * q + w][c0]);
+                    acc.x = __builtin_fmaf(f, v.x, acc.x);
+                    acc.y = __builtin_fmaf(f, v.y, acc.y);
+                    acc.z = __builtin_fmaf(f, v.z, acc.z);
+                    acc.w = __builtin_fmaf(f, v.w, acc.w);
+                }
             }
             out_full[n * 64 + lane] = make_float4(lrelu(acc.x, slope), lrelu(acc.y, slope), lrelu(acc.z, slope), lrelu(acc.w, slope));
         }
@@ -88,8 +96,13 @@ __global__ __launch_bounds__(kThreads) void k_encoder_front(const uint4 *__restr
         for (int p = 0; p < 4; ++p) {
             const int c = lane + 64 * p;
             const uint32_t kkkk = (uint32_t)(c >> 4) * 0x01010101u;
-            const uint32_t e0 = eq_flags(r[0], kkkk), e1 = eq_flags(r[1], kkkk), e2 = eq_flags(r[2], kkkk), e3 = eq_flags(r[3], kkkk);
-            const uint32_t e[4] = {e0, e1, e2, e3};
+            float f[4][4]; // f[row][col] = 1.0 where the cell has class k
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t eq = eq_bytes(r[q], kkkk);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) f[q][w] = byte_f32(eq, w);
+            }
             const float4 wr = *reinterpret_cast<const float4 *>(s_rows[c]);
             const float4 wc = *reinterpret_cast<const float4 *>(s_cols[c]);
             const float wrv[4] = {wr.x, wr.y, wr.z, wr.w}, wcv[4] = {wc.x, wc.y, wc.z, wc.w};
@@ -97,12 +110,13 @@ __global__ __launch_bounds__(kThreads) void k_encoder_front(const uint4 *__restr
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float a = s_br[c]; // row q: columns in ascending order
-#pragma unroll
-                for (int w = 0; w < 4; ++w) a += (e[q] & (0x80u << (8 * w))) ? wrv[w] : 0.0f;
-                rows[q] = a;
                 float d = s_bc[c]; // column q: rows in ascending order
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) d += (e[rr] & (0x80u << (8 * q))) ? wcv[rr] : 0.0f;
+                for (int t = 0; t < 4; ++t) {
+                    a = __builtin_fmaf(f[q][t], wrv[t], a);
+                    d = __builtin_fmaf(f[t][q], wcv[t], d);
+                }
+                rows[q] = a;
                 cols[q] = d;
             }
             out_rows[n * kCh + c] = make_float4(lrelu(rows[0], slope), lrelu(rows[1], slope), lrelu(rows[2], slope), lrelu(rows[3], slope));
