@@ -72,7 +72,9 @@ int ml2048_reset(void *stream, int64_t M, const ml2048_state *st);
  *   game_count    device int32, advanced by the number of resets (VecGame._game_count)
  *   n_reset       device int32 out: number of boards reset
  *   reset_indices device int64[M] out or NULL: the ascending slots (the tuple prepare() returns)
- *   scratch       device int32[ml2048_scratch_ints(M)]
+ *   scratch       device int32[ml2048_scratch_ints(M)], 8-byte aligned, ZEROED ONCE by the caller before its
+ *                 first use and then left alone: it holds the 64-bit status words of the single-pass ordered
+ *                 scan, which are tagged with a per-launch epoch and never need resetting between calls
  * randperm: device uint8[1024][16]; randfloat: device float[1024] (VecGame._randperm/_randfloat).
  */
 int ml2048_prepare(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st,

@@ -230,7 +230,7 @@ class VecGame:
         self._game_count_dev = torch.zeros((1,), dtype=i32, device=dev)  # :582 - survives reset()
         self._n_reset_dev = torch.zeros((1,), dtype=i32, device=dev)
         self._reset_indices = torch.empty((M,), dtype=torch.int64, device=dev)
-        self._scratch = torch.empty((int(self._L.ml2048_scratch_ints(M)),), dtype=i32, device=dev)
+        self._scratch = torch.zeros((int(self._L.ml2048_scratch_ints(M)),), dtype=i32, device=dev)  # zeroed once
         self._hist = torch.zeros((20,), dtype=i32, device=dev)
         self._fast_counter = 0
         self._devrng = torch.zeros((6,), dtype=torch.int64, device=dev)  # struct ml2048_devrng

@@ -36,8 +36,8 @@ def test_header_symbols_all_exported(lib):
 
 def test_version_and_sizes(lib):
     assert lib.ml2048_abi_version() == 1
-    assert lib.ml2048_scratch_ints(1) == 3
-    assert lib.ml2048_scratch_ints(65536) == 64 + 2
+    assert lib.ml2048_scratch_ints(1) == 4
+    assert lib.ml2048_scratch_ints(65536) == 2 * 64 + 2
     assert lib.ml2048_rollout_flag_words(65536) == 1024
     assert lib.ml2048_rollout_flag_words(65) == 4
     assert lib.ml2048_rollout_scratch_ints(65536, 128) == 128 * 1024 + 128 + 2
