@@ -56,6 +56,23 @@ def test_argument_validation_without_gpu(lib):
     assert b"aligned" in lib.ml2048_last_error()
     with pytest.raises(ValueError):
         _lib.check(lib.ml2048_sample_actions(None, -5, 0, None, 0, 0, 1, None, None), "sample")
+    # the later entry points reject bad arguments before any launch as well
+    ok = _lib.State(*([4096] * 11))
+    assert lib.ml2048_upload(None, None, None, 0, 0) == -1
+    assert lib.ml2048_upload(None, 4096, 4104, 64, 0) == -2              # src not 16-byte aligned
+    assert lib.ml2048_upload(None, 4096, 8192, 64, 5) == -1              # more table rows than bytes
+    assert lib.ml2048_rollout_chain(None, 64, 0, C.byref(ok), 8, None, None, 1, None, 0, 0, 0, 0, None, None,
+                                    None, None, 0, 0) == -1
+    assert lib.ml2048_rollout_chain(None, 64, 0, C.byref(ok), 8, 4096, 4096, 1, 4096, 0, 0, 0, 0, 4096, 4096,
+                                    8192, None, 64, 0) == -1              # next_dst missing
+    assert lib.ml2048_episode_stats(None, 64, C.byref(ok), None, None, 10, None, None, None) == -1
+    assert lib.ml2048_episode_stats(None, 64, C.byref(ok), 4096, 4096, -1, 4096, 4096, 4096) == -1
+    assert lib.ml2048_episode_stats(None, 64, C.byref(ok), 4100, 4096, 5, 4096, 4096, 4096) == -2   # age alignment
+    assert lib.ml2048_encoder_front(None, 0, None, None, None, None, None, None, None, 0.01, None, None, None) == -1
+    assert lib.ml2048_encoder_front(None, 8, 4100, 4096, 4096, 4096, 4096, 4096, 4096, 0.01, 4096, 4096, 4096) == -2
+    assert lib.ml2048_timer_arm(None) == -1 and lib.ml2048_timer_elapsed_ms(None, None) == -1
+    lib.ml2048_timer_destroy(None)
+    assert lib.ml2048_sched_stream_take(None, None, 0, None, None, None, None, None, None, None, None) == -1
 
 
 def test_python_api_fails_loudly_without_gpu():
