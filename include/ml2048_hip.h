@@ -243,6 +243,21 @@ int ml2048_devrng_schedule(void *stream, const void *workspace, ml2048_devrng *r
                            uint8_t *perm_epochs, uint32_t *two_masks, int32_t max_epochs, int32_t *n_epochs);
 
 /*
+ * The same schedule from data-parallel primitives (csrc/devrng2.hip): a window of 2^18 generator outputs by
+ * jump-ahead, the row-successor function of EVERY word position and its 4/16/64/256/1024-fold powers, one
+ * wavefront that follows the draw order with one table look-up per regeneration, and row-parallel swaps.
+ * Same arguments and results as ml2048_devrng_schedule; workspace: ml2048_devrng2_workspace_bytes() bytes,
+ * 256-byte aligned, prepared once by ml2048_devrng2_init (the schedule call reuses it as scratch).
+ * expanded_tables != 0: perm_epochs is uint8[max_epochs][1024][32] - each row followed by its inverse
+ * permutation in board layout, the table form ml2048_rollout_chain consumes.
+ */
+int64_t ml2048_devrng2_workspace_bytes(void);
+int ml2048_devrng2_init(void *stream, void *workspace);
+int ml2048_devrng2_schedule(void *stream, void *workspace, ml2048_devrng *rng, uint8_t *randperm, float *randfloat,
+                            int32_t n_steps, double two_prob, int32_t *schedule, uint8_t *perm_epochs,
+                            uint32_t *two_masks, int32_t max_epochs, int32_t *n_epochs, int expanded_tables);
+
+/*
  * Fused N-step rollout with on-device action sampling: the random-action loop
  *     for t in range(N): env.prepare(); a = policy.sample_actions(...); env.step(a)
  * (VecRunner.step_many with RandomPolicy, src/ml2048/runner.py:74-117, policy/random.py:17-27)

@@ -86,6 +86,10 @@ _SIGNATURES = {
     "ml2048_devrng_init": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ml2048_devrng_schedule": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "ml2048_devrng2_workspace_bytes": (C.c_int64, []),
+    "ml2048_devrng2_init": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ml2048_devrng2_schedule": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                          C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int]),
     "ml2048_rollout_flag_words": (C.c_int64, [C.c_int64]),
     "ml2048_rollout_scratch_ints": (C.c_int64, [C.c_int64, C.c_int32]),
     "ml2048_timer_create": (C.c_int, [C.POINTER(C.c_void_p)]),

@@ -27,6 +27,7 @@
 #include <stdint.h>
 
 #include "../../include/ml2048_hip.h"
+#include "board_ops.hpp"
 
 namespace {
 
@@ -104,12 +105,34 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
+// `cont` != NULL: CONTINUATION of a data-parallel schedule (csrc/devrng2.hip) whose window of generator outputs
+// ran out before step N (more than ~23 regenerations in 128 steps: rare, but it happens): cont[0] = epochs so
+// far, cont[1] = error, cont[4] = steps already done, cont[5] = "ran out" flag.  This kernel then finishes steps
+// cont[4]..N-1 from the generator state the other one left; when nothing is left it returns at once.
+// EXPANDED: 32-byte epoch rows (permutation + inverse) as ml2048_rollout_chain consumes them.
+template <bool EXPANDED>
+__device__ __forceinline__ void store_epoch_row1(uint8_t *perm_epochs, size_t epoch, int t, uint4 v) {
+    uint4 *out = reinterpret_cast<uint4 *>(perm_epochs);
+    if (EXPANDED) {
+        const uint32_t perm[4] = {v.x, v.y, v.z, v.w};
+        uint32_t inv[4];
+        ml2048::invert_perm_row(perm, inv);
+        out[2 * (epoch * kThreads + t)] = v;
+        out[2 * (epoch * kThreads + t) + 1] = make_uint4(inv[0], inv[1], inv[2], inv[3]);
+    } else {
+        out[epoch * kThreads + t] = v;
+    }
+}
+
+template <bool EXPANDED>
 __global__ __launch_bounds__(kThreads) void k_devrng_schedule(const Jump *__restrict__ ws, ml2048_devrng *rng,
                                                               uint8_t *randperm, float *randfloat, int N,
                                                               double two_prob, int32_t *__restrict__ schedule,
                                                               uint8_t *__restrict__ perm_epochs,
                                                               uint32_t *__restrict__ two_masks, int max_epochs,
-                                                              int32_t *__restrict__ n_epochs) {
+                                                              int32_t *__restrict__ n_epochs,
+                                                              const int32_t *__restrict__ cont) {
+    if (cont && (!cont[5] || cont[4] >= N || cont[1])) return; // nothing left for the continuation
     __shared__ uint32_t words[kWords + 8];       // the 32-bit words of the current window (96 KiB)
     __shared__ uint16_t acc_tab[16];
     __shared__ uint8_t seg_state[2][kRelax + 1]; // automaton state (i-1) at each segment start, ping-pong
@@ -126,22 +149,23 @@ __global__ __launch_bounds__(kThreads) void k_devrng_schedule(const Jump *__rest
     uint32_t buf32 = rng->uinteger;
     int rs = rng->rand_step;
     int err = 0;
+    const int step_begin = cont ? cont[4] : 0;
 
     if (t < 16) acc_tab[t] = (uint16_t)accept_bits((uint32_t)t);
     // my row of the table lives in two 64-bit registers for the whole kernel; epoch 0 of the output
     uint64_t row_lo, row_hi;
     {
         const uint4 v = reinterpret_cast<const uint4 *>(randperm)[t];
-        reinterpret_cast<uint4 *>(perm_epochs)[t] = v;
+        if (!cont) store_epoch_row1<EXPANDED>(perm_epochs, 0, t, v);
         row_lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
         row_hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
     }
-    if (wave == 0) {
+    if (wave == 0 && !cont) {
         const float f = randfloat[lane & 15];
         const unsigned long long m = __ballot((double)f < two_prob);
         if (lane == 0) two_masks[0] = (uint32_t)(m & 0xFFFFull);
     }
-    int E = 1;
+    int E = cont ? cont[0] : 1;
     const u128 myP = ws[t].P, myG = ws[t].G; // my jump to LCG step 12 t (loaded once)
     __syncthreads();
 #ifdef ML2048_DEVRNG_STATS
@@ -155,7 +179,7 @@ __global__ __launch_bounds__(kThreads) void k_devrng_schedule(const Jump *__rest
 
     const uint64_t kNine = 8106479329266893ull; // u >= 0.9  <=>  (out >> 11) >= 0.9 * 2^53 (exact)
 
-    for (int step = 0; step < N; ++step) {
+    for (int step = step_begin; step < N; ++step) {
         // ---- VecGame.prepare's draws (game_numba.py:622-626); every thread tracks the cursor
         cur = cur * A + inc;
         const uint64_t o = xsl_rr(cur);
@@ -297,8 +321,8 @@ __global__ __launch_bounds__(kThreads) void k_devrng_schedule(const Jump *__rest
                         --i;
                     }
                 }
-                reinterpret_cast<uint4 *>(perm_epochs)[(size_t)E * kThreads + t] =
-                    make_uint4((uint32_t)row_lo, (uint32_t)(row_lo >> 32), (uint32_t)row_hi, (uint32_t)(row_hi >> 32));
+                store_epoch_row1<EXPANDED>(perm_epochs, (size_t)E, t,
+                                           make_uint4((uint32_t)row_lo, (uint32_t)(row_lo >> 32), (uint32_t)row_hi, (uint32_t)(row_hi >> 32)));
             }
             ML_T(t_replay)
             // (5) Generator.random(float32): word used+t of the window
@@ -397,8 +421,26 @@ int ml2048_devrng_schedule(void *stream, const void *workspace, ml2048_devrng *r
         n_steps <= 0 || max_epochs <= 0)
         return ML2048_E_INVALID;
     if (((uintptr_t)workspace | (uintptr_t)randperm | (uintptr_t)perm_epochs) % 16) return ML2048_E_ALIGN;
-    hipLaunchKernelGGL(k_devrng_schedule, dim3(1), dim3(kThreads), 0, (hipStream_t)stream, (const Jump *)workspace, rng,
-                       randperm, randfloat, n_steps, two_prob, schedule, perm_epochs, two_masks, max_epochs, n_epochs);
+    hipLaunchKernelGGL((k_devrng_schedule<false>), dim3(1), dim3(kThreads), 0, (hipStream_t)stream, (const Jump *)workspace, rng,
+                       randperm, randfloat, n_steps, two_prob, schedule, perm_epochs, two_masks, max_epochs, n_epochs,
+                       (const int32_t *)nullptr);
+    return (int)hipGetLastError();
+}
+
+// internal: the continuation launch of ml2048_devrng2_schedule (see k_devrng_schedule); `jump_ws` is a workspace
+// prepared by ml2048_devrng_init
+int ml2048_internal_devrng_continue(void *stream, const void *jump_ws, ml2048_devrng *rng, uint8_t *randperm,
+                                    float *randfloat, int32_t n_steps, double two_prob, int32_t *schedule,
+                                    uint8_t *perm_epochs, uint32_t *two_masks, int32_t max_epochs, int32_t *n_epochs,
+                                    const int32_t *cont, int expanded) {
+    if (expanded)
+        hipLaunchKernelGGL((k_devrng_schedule<true>), dim3(1), dim3(kThreads), 0, (hipStream_t)stream, (const Jump *)jump_ws,
+                           rng, randperm, randfloat, n_steps, two_prob, schedule, perm_epochs, two_masks, max_epochs,
+                           n_epochs, cont);
+    else
+        hipLaunchKernelGGL((k_devrng_schedule<false>), dim3(1), dim3(kThreads), 0, (hipStream_t)stream, (const Jump *)jump_ws,
+                           rng, randperm, randfloat, n_steps, two_prob, schedule, perm_epochs, two_masks, max_epochs,
+                           n_epochs, cont);
     return (int)hipGetLastError();
 }
 

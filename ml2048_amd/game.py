@@ -16,6 +16,7 @@ Differences from the reference, all deliberate and documented in DESIGN.md:
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Any, Optional, TypedDict
 
 import numpy as np
@@ -650,15 +651,21 @@ class VecGame:
         return int(out.item()) & 0xFFFFFFFFFFFFFFFF
 
     # ------------------------------------------------------------------------------------------
-    def _device_schedule(self, N: int):
-        """Enqueue the GPU computation of the next N-step draw schedule (csrc/devrng.hip) and return
-        device views (perm_epochs, schedule, two_masks, max_epochs).  The schedule kernel runs on a
-        side stream, one slot ahead is possible: the rollout stream only waits for its own slot."""
+    def _device_schedule(self, N: int, expanded: bool = False):
+        """Enqueue the GPU computation of the next N-step draw schedule (csrc/devrng2.hip) and return
+        device views (perm_epochs, schedule, two_masks, max_epochs).  The schedule kernels run on a
+        side stream, one slot ahead is possible: the rollout stream only waits for its own slot.
+        expanded: epoch tables as 32-byte rows (permutation + inverse), for ml2048_rollout_chain."""
         L, dev = self._L, self.device
         if self._devrng_ws is None:
-            self._devrng_ws = torch.empty((int(L.ml2048_devrng_workspace_bytes()),), dtype=torch.uint8, device=dev)
+            # default: the data-parallel generation (csrc/devrng2.hip); ML2048_DEVRNG=1 selects the original
+            # single-workgroup kernel (csrc/devrng.hip) for comparison
+            self._devrng_v1 = os.environ.get("ML2048_DEVRNG", "2") == "1"
+            nbytes = int(L.ml2048_devrng_workspace_bytes() if self._devrng_v1 else L.ml2048_devrng2_workspace_bytes())
+            self._devrng_ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
             with self._dev_ctx():
-                _lib.check(L.ml2048_devrng_init(self._stream(), self._devrng_ws.data_ptr()), "devrng_init")
+                init = L.ml2048_devrng_init if self._devrng_v1 else L.ml2048_devrng2_init
+                _lib.check(init(self._stream(), self._devrng_ws.data_ptr()), "devrng_init")
         self._push_rng()
         cap = N + 1  # one epoch per step at most: can never overflow
         if self._sched_slots is None or self._sched_slots[0] != N:
@@ -669,7 +676,7 @@ class VecGame:
             slots = []
             for _ in range(2):  # double-buffered outputs
                 slots.append({
-                    "perm": torch.empty((cap, RAND_SIZE, 16), dtype=torch.uint8, device=dev),
+                    "perm": torch.empty((cap, RAND_SIZE, 32), dtype=torch.uint8, device=dev),  # room for the expanded form
                     "sched": torch.empty((N, 3), dtype=torch.int32, device=dev),
                     "mask": torch.empty((cap,), dtype=torch.int32, device=dev),
                     "ne": torch.zeros((1,), dtype=torch.int32, device=dev),
@@ -691,15 +698,22 @@ class VecGame:
             side.wait_event(push)
             self._rng_push_event = None
         with self._dev_ctx():
-            _lib.check(L.ml2048_devrng_schedule(
-                side.cuda_stream, self._devrng_ws.data_ptr(), self._devrng.data_ptr(), self._randperm_dev.data_ptr(),
-                self._randfloat_dev.data_ptr(), N, self._two_prob, slot["sched"].data_ptr(), slot["perm"].data_ptr(),
-                slot["mask"].data_ptr(), cap, slot["ne"].data_ptr()), "devrng_schedule")
+            args = (side.cuda_stream, self._devrng_ws.data_ptr(), self._devrng.data_ptr(), self._randperm_dev.data_ptr(),
+                    self._randfloat_dev.data_ptr(), N, self._two_prob, slot["sched"].data_ptr(), slot["perm"].data_ptr(),
+                    slot["mask"].data_ptr(), cap, slot["ne"].data_ptr())
+            if self._devrng_v1:
+                expanded = False
+                _lib.check(L.ml2048_devrng_schedule(*args), "devrng_schedule")
+            else:
+                _lib.check(L.ml2048_devrng2_schedule(*args, int(expanded)), "devrng2_schedule")
+        if os.environ.get("ML2048_DEBUG_SYNC_SCHED"):
+            side.synchronize()
         ready = torch.cuda.Event()
         ready.record(side)
         main.wait_event(ready)
         self._sched_pending_slot = slot
-        return slot["perm"], slot["sched"], slot["mask"], cap
+        perm = slot["perm"] if expanded else slot["perm"].view(-1)[:cap * RAND_SIZE * 16].view(cap, RAND_SIZE, 16)
+        return perm, slot["sched"], slot["mask"], cap, expanded
 
     def rollout(self, n_steps: int, *, masked: bool = True, act_seed: int = 0, act_counter: int = 0,
                 record_actions: bool = False, digests: bool = False, finish_ids=True,
@@ -730,8 +744,10 @@ class VecGame:
         L = self._L
         fast = self._spawn != "table"
         on_device = (not fast) and self._schedule_mode == "device"
+        dev_expanded = False
         if on_device:
-            perm_dev, sched_dev, mask_dev, E = self._device_schedule(N)
+            plain = trajectory is None and not record_actions and not digests
+            perm_dev, sched_dev, mask_dev, E, dev_expanded = self._device_schedule(N, expanded=plain)
         elif not fast:
             # The host schedule does not depend on game state: it is packed as [epoch tables | schedule |
             # masks] in pinned memory and brought to the device by a kernel on THIS stream - either a
@@ -829,6 +845,11 @@ class VecGame:
                     self._fast_counter, self._reward_kind, int(masked), int(act_seed), int(act_counter),
                     a_ptr, d_ptr, flags.data_ptr(), last.data_ptr()), "rollout_fast")
                 self._fast_counter += N
+            elif on_device and dev_expanded:  # tables with inverse rows straight from the device schedule
+                _lib.check(L.ml2048_rollout_chain(
+                    self._stream(join=False), M, self._idx_base, self._st(), N, perm_dev.data_ptr(), mask_dev.data_ptr(),
+                    E, sched_dev.data_ptr(), self._reward_kind, int(masked), int(act_seed), int(act_counter),
+                    flags.data_ptr(), last.data_ptr(), None, None, 0, 0), "rollout_chain")
             elif not on_device and chain is not None:
                 _lib.check(L.ml2048_rollout_chain(
                     self._stream(join=False), M, self._idx_base, self._st(), N, perm_dev.data_ptr(), mask_dev.data_ptr(),
@@ -840,10 +861,10 @@ class VecGame:
                     self._stream(join=False), M, self._idx_base, self._st(), N, perm_dev.data_ptr(), mask_dev.data_ptr(),
                     E, sched_dev.data_ptr(), self._reward_kind, int(masked), int(act_seed), int(act_counter),
                     a_ptr, d_ptr, flags.data_ptr(), last.data_ptr()), "rollout")
-                if on_device:  # the slot may be overwritten once this rollout has consumed it
-                    ev = torch.cuda.Event()
-                    ev.record(torch.cuda.current_stream(dev))
-                    self._sched_pending_slot["free"] = ev
+            if on_device:  # (every launch variant) the slot may be overwritten once this rollout has consumed it
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                self._sched_pending_slot["free"] = ev
             if kernel_events is not None:
                 kernel_events[1].record(torch.cuda.current_stream(dev))
             roll_ev = None

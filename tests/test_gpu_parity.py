@@ -376,7 +376,9 @@ def test_rollout_fast_mode_vs_oracle(amd, oracle):
 
 
 # ---- the PCG64 draw schedule computed on the GPU (csrc/devrng.hip) --------------------------------------
-@pytest.mark.parametrize("seed", [0, 12345, 20241008, 987654321])
+# seed 519423726 draws 26 table regenerations in its first 128 steps: more than one window of generator outputs
+# covers, so the data-parallel kernels hand the rest of the schedule to the single-workgroup continuation
+@pytest.mark.parametrize("seed", [0, 12345, 20241008, 987654321, 519423726])
 def test_device_schedule_equals_host_schedule(amd, torch_cuda, seed):
     """Schedule, epoch tables, 2/4 masks, final generator state, tables and rand_step: the device
     kernel against the native host implementation (itself checked against numpy)."""
@@ -386,7 +388,7 @@ def test_device_schedule_equals_host_schedule(amd, torch_cuda, seed):
     env.reset(seed)
     ref = HostRng(seed)
     for n in (128, 1, 7, 300, 128, 1100):
-        perm, sched, mask, cap = env._device_schedule(n)
+        perm, sched, mask, cap, _ = env._device_schedule(n)
         torch_cuda.cuda.synchronize()
         ne = int(env._sched_pending_slot["ne"].item())
         s2, e2, m2 = ref.draw_schedule(n, 0.8)
