@@ -16,8 +16,9 @@
 //           words each, so 64 lanes test the next 64 steps' float64 draws at once; a regeneration is one
 //           look-up in L5, sixteen float words and a cursor update;
 //   rows    one thread per (regeneration, row): the row's start from the level tables (<= 15 look-ups),
-//           then its accepted words -> 15 swap targets packed in a 64-bit word;
-//   apply   one thread per table row: the swaps of all regenerations in order, epoch tables out.
+//           then its accepted words -> 15 swap targets -> the row's shuffle as a permutation of 16 bytes;
+//   apply   sixteen lanes per table row: a scan of permutation compositions over the regenerations
+//           (v_perm_b32), every epoch's table out at once.
 //
 // Long schedules run as segments of <= 128 steps, each on a fresh window at the generator's then-current
 // state.  Everything is checked bit for bit against the host schedule (tests/test_gpu_parity.py
@@ -25,6 +26,11 @@
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
 
 #include "../../include/ml2048_hip.h"
 #include "board_ops.hpp"
@@ -54,17 +60,18 @@ struct Jump2 {
     u128 P, G; // state after k steps = P s + G c
 };
 
-// workspace: [Jump2 pow2[24]] [control: int32 x 16] [F: kWordsW + 64 words] [L: kLevels x kWordsW]
-//            [regens: max 256 x 4 words] [js: 256 x 1024 x uint64]
+// workspace: [Jump2 pow2[24]] [Jump2 jt[2^18/16]] [control: int32 x 16] [F: kWordsW + 64 words] [L: kLevels x kWordsW]
+//            [regens: max 256 x 4 words] [sig: 256 x 1024 x 16 bytes]
 constexpr int kMaxRegens = 256;
 struct Layout {
     Jump2 *pow2;
+    Jump2 *jt;   // jt[t] = jump by kGenPerThread * t steps, one entry per k2_gen thread
     int32_t *ctl; // [0] E (running epoch count), [1] error, [2] regens in this segment, [3] first epoch of the segment,
                   // [4] steps done so far, [5] "the window ran out": the remaining steps go to the continuation
     uint32_t *F;
     uint32_t *L[kLevels];
     uint32_t *regens; // per regeneration of the segment: vstart, pending flag, pending word, float position
-    uint64_t *js;
+    uint4 *sig;      // per (regeneration, row): Generator.permuted's shuffle of that row as a permutation
     void *v1ws;       // jump tables of the single-workgroup kernel (csrc/devrng.hip), the continuation
 };
 __host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -73,6 +80,8 @@ __host__ __device__ inline Layout layout_of(void *ws) {
     Layout l;
     l.pow2 = (Jump2 *)p;
     p += align256(sizeof(Jump2) * 24);
+    l.jt = (Jump2 *)p;
+    p += align256(sizeof(Jump2) * (kSteps / kGenPerThread));
     l.ctl = (int32_t *)p;
     p += 256;
     l.F = (uint32_t *)p;
@@ -83,22 +92,19 @@ __host__ __device__ inline Layout layout_of(void *ws) {
     }
     l.regens = (uint32_t *)p;
     p += align256((size_t)kMaxRegens * 16);
-    l.js = (uint64_t *)p;
-    p += (size_t)kMaxRegens * ML2048_RAND_SIZE * 8;
+    l.sig = (uint4 *)p;
+    p += (size_t)kMaxRegens * ML2048_RAND_SIZE * 16;
     l.v1ws = p;
     return l;
 }
 inline size_t workspace_bytes() {
-    return align256(sizeof(Jump2) * 24) + 256 + align256((size_t)(kWordsW + 64) * 4) + kLevels * align256((size_t)kWordsW * 4) +
-           align256((size_t)kMaxRegens * 16) + (size_t)kMaxRegens * ML2048_RAND_SIZE * 8 +
+    return align256(sizeof(Jump2) * 24) + align256(sizeof(Jump2) * (kSteps / kGenPerThread)) + 256 + align256((size_t)(kWordsW + 64) * 4) + kLevels * align256((size_t)kWordsW * 4) +
+           align256((size_t)kMaxRegens * 16) + (size_t)kMaxRegens * ML2048_RAND_SIZE * 16 +
            align256((size_t)ml2048_devrng_workspace_bytes());
 }
 
-__global__ void k2_init(Jump2 *pow2) {
-    const int t = threadIdx.x;
-    if (t >= 24) return;
+__device__ __forceinline__ Jump2 jump_of(uint32_t k) {
     const u128 A = lcg_mul2();
-    uint32_t k = 1u << t;
     u128 accP = 1, accG = 0, curP = A, curG = 1;
     while (k) {
         if (k & 1u) {
@@ -109,8 +115,16 @@ __global__ void k2_init(Jump2 *pow2) {
         curP = curP * curP;
         k >>= 1;
     }
-    pow2[t].P = accP;
-    pow2[t].G = accG;
+    Jump2 j;
+    j.P = accP;
+    j.G = accG;
+    return j;
+}
+
+__global__ __launch_bounds__(256) void k2_init(Jump2 *pow2, Jump2 *jt) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < 24) pow2[t] = jump_of(1u << t);
+    if (t < kSteps / kGenPerThread) jt[t] = jump_of(t * kGenPerThread);
 }
 
 __device__ __forceinline__ u128 jump2(u128 s, u128 c, uint32_t k, const Jump2 *__restrict__ pow2) {
@@ -127,7 +141,8 @@ __global__ __launch_bounds__(256) void k2_gen(Layout l, const ml2048_devrng *__r
     const u128 cur = ((u128)rng->state_hi << 64) | rng->state_lo;
     const u128 inc = ((u128)rng->inc_hi << 64) | rng->inc_lo;
     const u128 A = lcg_mul2();
-    u128 st = jump2(cur, inc, k0, l.pow2);
+    const Jump2 jmp = l.jt[gid];
+    u128 st = jmp.P * cur + jmp.G * inc;
     uint2 *dst = reinterpret_cast<uint2 *>(l.F) + k0;
 #pragma unroll 4
     for (int j = 0; j < kGenPerThread; ++j) {
@@ -345,10 +360,29 @@ __global__ __launch_bounds__(256) void k2_rows(Layout l) {
             --i;
         }
     }
-    l.js[(size_t)e * ML2048_RAND_SIZE + r] = js;
+    // Generator.permuted's swaps (i = 15..1: d[i] <-> d[j]) applied to the identity row: the row's permutation sigma,
+    // so that "table row after this regeneration" = (row before) o sigma, a composition k2_apply can scan
+    uint64_t row_lo = 0x0706050403020100ull, row_hi = 0x0F0E0D0C0B0A0908ull;
+    // NOT unrolled on purpose: the fully unrolled form (constant shifts) of this 64-bit xor-swap chain gave wrong
+    // rows in part of one wavefront, only while other kernels shared the GPU (the swap targets and the input rows
+    // were verified correct, the non-unrolled loop never fails: tools/debug/fuzz_device2.py); cause not isolated
+#pragma unroll 1
+    for (uint32_t i2 = 15; i2 >= 1; --i2) {
+        const uint32_t j = (uint32_t)(js >> (4 * i2)) & 15u;
+        const uint64_t hi_i = i2 >= 8u ? row_hi : row_lo, hi_j = j >= 8u ? row_hi : row_lo;
+        const uint32_t si = 8u * (i2 & 7u), sj = 8u * (j & 7u);
+        const uint64_t x = ((hi_i >> si) ^ (hi_j >> sj)) & 0xFFull;
+        const uint64_t xi = x << si, xj = x << sj;
+        row_lo ^= (i2 < 8u ? xi : 0ull) ^ (j < 8u ? xj : 0ull);
+        row_hi ^= (i2 >= 8u ? xi : 0ull) ^ (j >= 8u ? xj : 0ull);
+    }
+    l.sig[(size_t)e * ML2048_RAND_SIZE + r] =
+        make_uint4((uint32_t)row_lo, (uint32_t)(row_lo >> 32), (uint32_t)row_hi, (uint32_t)(row_hi >> 32));
 }
 
-// ---- apply: Generator.permuted's swaps (i = 15..1: d[i] <-> d[j]) of all regenerations on one table row
+// ---- apply: every table row through all regenerations of the segment, epoch tables out.
+// Sixteen lanes per row: lane c holds the permutation of regeneration 16*chunk + c, an inclusive scan of
+// compositions over the sixteen lanes (four rounds) gives every epoch's row at once.
 // EXPANDED: epoch tables as 32-byte rows = the permutation + its inverse in board layout (what
 // ml2048_rollout_chain consumes, board_ops.hpp spawn_table_inv)
 template <bool EXPANDED>
@@ -365,35 +399,51 @@ __device__ __forceinline__ void store_epoch_row(uint8_t *perm_epochs, size_t epo
     }
 }
 
+// out[k] = left[sel[k]] on 16-byte rows of values 0..15 (two v_perm_b32 + a blend per dword)
+__device__ __forceinline__ uint4 compose_rows(uint4 left, uint4 sel) {
+    const uint32_t s[4] = {sel.x, sel.y, sel.z, sel.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t s7 = s[q] & 0x07070707u;
+        const uint32_t lo = __builtin_amdgcn_perm(left.y, left.x, s7); // bytes 0..7 of left
+        const uint32_t hi = __builtin_amdgcn_perm(left.w, left.z, s7); // bytes 8..15
+        const uint32_t m = ((s[q] >> 3) & 0x01010101u) * 0xFFu;
+        o[q] = (hi & m) | (lo & ~m);
+    }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+constexpr int kApplyLanes = 16;
 template <bool EXPANDED>
 __global__ __launch_bounds__(256) void k2_apply(Layout l, uint8_t *__restrict__ randperm, uint8_t *__restrict__ perm_epochs) {
-    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= ML2048_RAND_SIZE) return;
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t r = gid / kApplyLanes, c = gid % kApplyLanes;
     const int n_reg = l.ctl[2], E_in = l.ctl[3];
-    const uint4 v = reinterpret_cast<const uint4 *>(randperm)[r];
-    store_epoch_row<EXPANDED>(perm_epochs, (size_t)(E_in - 1), r, v); // the table at entry
+    uint4 row = reinterpret_cast<const uint4 *>(randperm)[r];
+    if (c == 0) store_epoch_row<EXPANDED>(perm_epochs, (size_t)(E_in - 1), r, row); // the table at entry
     if (l.ctl[1]) return;
-    uint64_t row_lo = (uint64_t)v.x | ((uint64_t)v.y << 32), row_hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
-    for (int e = 0; e < n_reg; ++e) {
-        const uint64_t js = l.js[(size_t)e * ML2048_RAND_SIZE + r];
-        // NOT unrolled on purpose: the fully unrolled form (constant shifts) of this 64-bit xor-swap chain gave wrong
-        // rows in part of one wavefront, only while other kernels shared the GPU (js and the input rows were
-        // verified correct, the non-unrolled loop never fails: tools/debug/fuzz_device2.py); cause not isolated
-#pragma unroll 1
-        for (uint32_t i = 15; i >= 1; --i) {
-            const uint32_t j = (uint32_t)(js >> (4 * i)) & 15u;
-            const uint64_t hi_i = i >= 8u ? row_hi : row_lo, hi_j = j >= 8u ? row_hi : row_lo;
-            const uint32_t si = 8u * (i & 7u), sj = 8u * (j & 7u);
-            const uint64_t x = ((hi_i >> si) ^ (hi_j >> sj)) & 0xFFull;
-            const uint64_t xi = x << si, xj = x << sj;
-            row_lo ^= (i < 8u ? xi : 0ull) ^ (j < 8u ? xj : 0ull);
-            row_hi ^= (i >= 8u ? xi : 0ull) ^ (j >= 8u ? xj : 0ull);
+    const uint4 ident = make_uint4(0x03020100u, 0x07060504u, 0x0B0A0908u, 0x0F0E0D0Cu);
+    for (int e0 = 0; e0 < n_reg; e0 += kApplyLanes) {
+        const int e = e0 + (int)c;
+        uint4 P = e < n_reg ? l.sig[(size_t)e * ML2048_RAND_SIZE + r] : ident;
+#pragma unroll
+        for (int d = 1; d < kApplyLanes; d *= 2) {
+            uint4 left;
+            left.x = __shfl_up(P.x, d, kApplyLanes);
+            left.y = __shfl_up(P.y, d, kApplyLanes);
+            left.z = __shfl_up(P.z, d, kApplyLanes);
+            left.w = __shfl_up(P.w, d, kApplyLanes);
+            if ((int)c >= d) P = compose_rows(left, P);
         }
-        store_epoch_row<EXPANDED>(perm_epochs, (size_t)(E_in + e), r,
-                                  make_uint4((uint32_t)row_lo, (uint32_t)(row_lo >> 32), (uint32_t)row_hi, (uint32_t)(row_hi >> 32)));
+        const uint4 mine = compose_rows(row, P);
+        if (e < n_reg) store_epoch_row<EXPANDED>(perm_epochs, (size_t)(E_in + e), r, mine);
+        row.x = __shfl(mine.x, kApplyLanes - 1, kApplyLanes); // lanes past n_reg hold the identity: lane 15 = last
+        row.y = __shfl(mine.y, kApplyLanes - 1, kApplyLanes);
+        row.z = __shfl(mine.z, kApplyLanes - 1, kApplyLanes);
+        row.w = __shfl(mine.w, kApplyLanes - 1, kApplyLanes);
     }
-    reinterpret_cast<uint4 *>(randperm)[r] =
-        make_uint4((uint32_t)row_lo, (uint32_t)(row_lo >> 32), (uint32_t)row_hi, (uint32_t)(row_hi >> 32));
+    if (c == 0) reinterpret_cast<uint4 *>(randperm)[r] = row;
 }
 
 } // namespace
@@ -410,19 +460,15 @@ int ml2048_internal_devrng_continue(void *stream, const void *jump_ws, ml2048_de
 int ml2048_devrng2_init(void *stream, void *workspace) {
     if (!workspace || (uintptr_t)workspace % 256) return ML2048_E_ALIGN;
     const Layout l = layout_of(workspace);
-    hipLaunchKernelGGL(k2_init, dim3(1), dim3(64), 0, (hipStream_t)stream, l.pow2);
+    hipLaunchKernelGGL(k2_init, dim3(kSteps / kGenPerThread / 256), dim3(256), 0, (hipStream_t)stream, l.pow2, l.jt);
     if (int rc = ml2048_devrng_init(stream, l.v1ws)) return rc;
     return (int)hipGetLastError();
 }
 
-int ml2048_devrng2_schedule(void *stream, void *workspace, ml2048_devrng *rng, uint8_t *randperm, float *randfloat,
+// The launches of one schedule (gen, succ, 5 levels, walk, rows, apply per segment + the continuation).
+static int enqueue_schedule(hipStream_t s, void *workspace, ml2048_devrng *rng, uint8_t *randperm, float *randfloat,
                             int32_t n_steps, double two_prob, int32_t *schedule, uint8_t *perm_epochs,
                             uint32_t *two_masks, int32_t max_epochs, int32_t *n_epochs, int expanded_tables) {
-    if (!workspace || !rng || !randperm || !randfloat || !schedule || !perm_epochs || !two_masks || !n_epochs ||
-        n_steps <= 0 || max_epochs <= 0)
-        return ML2048_E_INVALID;
-    if ((uintptr_t)workspace % 256 || ((uintptr_t)randperm | (uintptr_t)perm_epochs) % 16) return ML2048_E_ALIGN;
-    hipStream_t s = (hipStream_t)stream;
     const Layout l = layout_of(workspace);
     for (int step0 = 0; step0 < n_steps; step0 += kSegSteps) {
         const int n_seg = n_steps - step0 < kSegSteps ? n_steps - step0 : kSegSteps;
@@ -434,14 +480,91 @@ int ml2048_devrng2_schedule(void *stream, void *workspace, ml2048_devrng *rng, u
                            two_masks, max_epochs, step0 == 0 ? 1 : 0, n_epochs);
         hipLaunchKernelGGL(k2_rows, dim3(kMaxRegens * ML2048_RAND_SIZE / 256), dim3(256), 0, s, l);
         if (expanded_tables)
-            hipLaunchKernelGGL((k2_apply<true>), dim3(ML2048_RAND_SIZE / 256), dim3(256), 0, s, l, randperm, perm_epochs);
+            hipLaunchKernelGGL((k2_apply<true>), dim3(ML2048_RAND_SIZE * kApplyLanes / 256), dim3(256), 0, s, l, randperm, perm_epochs);
         else
-            hipLaunchKernelGGL((k2_apply<false>), dim3(ML2048_RAND_SIZE / 256), dim3(256), 0, s, l, randperm, perm_epochs);
+            hipLaunchKernelGGL((k2_apply<false>), dim3(ML2048_RAND_SIZE * kApplyLanes / 256), dim3(256), 0, s, l, randperm, perm_epochs);
     }
     // If a window ran out (an unusual number of regenerations), the single-workgroup kernel finishes the remaining
     // steps from the state reached; otherwise it returns at once.
-    if (int rc = ml2048_internal_devrng_continue(stream, l.v1ws, rng, randperm, randfloat, n_steps, two_prob, schedule,
-                                                 perm_epochs, two_masks, max_epochs, n_epochs, l.ctl, expanded_tables))
+    return ml2048_internal_devrng_continue((void *)s, l.v1ws, rng, randperm, randfloat, n_steps, two_prob, schedule,
+                                           perm_epochs, two_masks, max_epochs, n_epochs, l.ctl, expanded_tables);
+}
+
+// One schedule is 11+ small dependent launches whose arguments repeat from call to call (two output slots in
+// game.py): the host cost of enqueueing them one by one (~170 us per 128-step schedule, measured) exceeded the
+// rollout kernel they feed.  The chain is captured once per argument set into a hipGraph and replayed with a
+// single hipGraphLaunch.  ML2048_DEVRNG_GRAPH=0 keeps the direct launches.
+struct GraphKey {
+    void *ws, *rng, *randperm, *randfloat, *schedule, *perm_epochs, *two_masks, *n_epochs;
+    double two_prob;
+    int32_t n_steps, max_epochs, expanded;
+    bool operator==(const GraphKey &o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
+};
+struct GraphEntry {
+    GraphKey key;
+    hipGraphExec_t exec;
+    uint64_t last_use;
+};
+constexpr size_t kGraphCache = 8;
+static std::mutex g_graph_mu;
+static std::vector<GraphEntry> g_graphs;
+static uint64_t g_graph_clock = 0;
+
+static bool graphs_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("ML2048_DEVRNG_GRAPH");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+int ml2048_devrng2_schedule(void *stream, void *workspace, ml2048_devrng *rng, uint8_t *randperm, float *randfloat,
+                            int32_t n_steps, double two_prob, int32_t *schedule, uint8_t *perm_epochs,
+                            uint32_t *two_masks, int32_t max_epochs, int32_t *n_epochs, int expanded_tables) {
+    if (!workspace || !rng || !randperm || !randfloat || !schedule || !perm_epochs || !two_masks || !n_epochs ||
+        n_steps <= 0 || max_epochs <= 0)
+        return ML2048_E_INVALID;
+    if ((uintptr_t)workspace % 256 || ((uintptr_t)randperm | (uintptr_t)perm_epochs) % 16) return ML2048_E_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    if (s != nullptr && graphs_enabled()) { // the NULL stream cannot be captured
+        GraphKey key;
+        memset(&key, 0, sizeof(key));
+        key.ws = workspace, key.rng = rng, key.randperm = randperm, key.randfloat = randfloat, key.schedule = schedule;
+        key.perm_epochs = perm_epochs, key.two_masks = two_masks, key.n_epochs = n_epochs, key.two_prob = two_prob;
+        key.n_steps = n_steps, key.max_epochs = max_epochs, key.expanded = expanded_tables ? 1 : 0;
+        std::lock_guard<std::mutex> lock(g_graph_mu);
+        for (GraphEntry &g : g_graphs)
+            if (g.key == key) {
+                g.last_use = ++g_graph_clock;
+                return (int)hipGraphLaunch(g.exec, s);
+            }
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const int rc = enqueue_schedule(s, workspace, rng, randperm, randfloat, n_steps, two_prob, schedule, perm_epochs,
+                                            two_masks, max_epochs, n_epochs, expanded_tables);
+            hipGraph_t graph = nullptr;
+            hipError_t e = hipStreamEndCapture(s, &graph);
+            hipGraphExec_t exec = nullptr;
+            if (e == hipSuccess && rc == 0) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            if (graph) (void)hipGraphDestroy(graph);
+            if (rc) return rc;
+            if (e == hipSuccess) {
+                if (g_graphs.size() >= kGraphCache) {
+                    size_t oldest = 0;
+                    for (size_t i = 1; i < g_graphs.size(); ++i)
+                        if (g_graphs[i].last_use < g_graphs[oldest].last_use) oldest = i;
+                    (void)hipGraphExecDestroy(g_graphs[oldest].exec);
+                    g_graphs.erase(g_graphs.begin() + (long)oldest);
+                }
+                g_graphs.push_back(GraphEntry{key, exec, ++g_graph_clock});
+                return (int)hipGraphLaunch(exec, s);
+            }
+            (void)hipGetLastError(); // capture or instantiation refused: fall through to the direct launches
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if (int rc = enqueue_schedule(s, workspace, rng, randperm, randfloat, n_steps, two_prob, schedule, perm_epochs,
+                                  two_masks, max_epochs, n_epochs, expanded_tables))
         return rc;
     return (int)hipGetLastError();
 }

@@ -674,7 +674,8 @@ class VecGame:
                     for key in ("perm", "sched", "mask", "ne"):
                         old[key].record_stream(self._sched_stream)
             slots = []
-            for _ in range(2):  # double-buffered outputs
+            for _ in range(3):  # a ring of three: generation k+1 must not wait for the rollout that read slot k-1
+                # (with two, each cross-stream hand-over - about 20 us - sat on the critical path twice per period)
                 slots.append({
                     "perm": torch.empty((cap, RAND_SIZE, 32), dtype=torch.uint8, device=dev),  # room for the expanded form
                     "sched": torch.empty((N, 3), dtype=torch.int32, device=dev),
@@ -688,11 +689,11 @@ class VecGame:
             self._sched_stream.wait_stream(torch.cuda.current_stream(dev))  # workspace init, fresh buffers
         _, slots, k = self._sched_slots
         slot = slots[k]
-        self._sched_slots = (N, slots, k ^ 1)
+        self._sched_slots = (N, slots, (k + 1) % len(slots))
         main = torch.cuda.current_stream(dev)
         side = self._sched_stream
         if slot["free"] is not None:
-            side.wait_event(slot["free"])  # its previous consumer (two rollouts ago) has finished
+            side.wait_event(slot["free"])  # its previous consumer (three rollouts ago) has finished
         push = getattr(self, "_rng_push_event", None)
         if push is not None:
             side.wait_event(push)
