@@ -250,6 +250,10 @@ int ml2048_devrng_schedule(void *stream, const void *workspace, ml2048_devrng *r
  * 256-byte aligned, prepared once by ml2048_devrng2_init (the schedule call reuses it as scratch).
  * expanded_tables != 0: perm_epochs is uint8[max_epochs][1024][32] - each row followed by its inverse
  * permutation in board layout, the table form ml2048_rollout_chain consumes.
+ * On a non-NULL stream the dozen dependent launches of one call are captured once per argument set into a
+ * hipGraph (the library keeps the last 8) and replayed with one hipGraphLaunch; calls with repeating
+ * arguments (a ring of output buffers) therefore cost one enqueue.  ML2048_DEVRNG_GRAPH=0 in the environment
+ * keeps the direct launches.  The workspace must stay allocated while such calls may repeat.
  */
 int64_t ml2048_devrng2_workspace_bytes(void);
 int ml2048_devrng2_init(void *stream, void *workspace);
