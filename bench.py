@@ -38,8 +38,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)  # 0.12 s timed at C2: long enough to average out host jitter
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--boards", type=int, default=65536, help="M per GPU (C2: 65536)")
     ap.add_argument("--env-steps", type=int, default=128, help="N env steps per bench step (C2: 128)")
     ap.add_argument("--mode", choices=["fused", "fused-traj", "stepwise", "obs"], default="fused",

@@ -474,6 +474,12 @@ struct StepRegs {
     uint32_t terminated; // written only on a valid move
 };
 
+// score accumulates reward_fn_normal whatever reward_fn is (:729-731).  The reference computes f32 + f64 -> f64 -> f32
+// (H8).  The added value is an integer < 2^22 (eight merges of at most 2^18) and the score a float32, so the float64 sum
+// is exact and its conversion is the one rounding of the exact sum - which is what a float32 addition returns (RNE).
+// One v_add_f32 instead of two conversions, a 64-bit add and a conversion back.
+ML_HD float add_score(float score, uint32_t sum_value) { return score + (float)sum_value; }
+
 ML_HD bool step_pre(StepRegs &s, uint32_t action, int reward_kind) {
     // H11: an out-of-range action is treated as invalid (the reference would read out of bounds)
     bool ok = action < 4u && ((s.valid >> (8u * (action & 3u))) & 0xFFu) != 0u;
@@ -488,8 +494,7 @@ ML_HD bool step_pre(StepRegs &s, uint32_t action, int reward_kind) {
     s.merged[3] = st.merged[3];
     s.step += 1;
     s.reward = (float)reward_value(reward_kind, mv.board, prev, st);
-    // score accumulates reward_fn_normal whatever reward_fn is (:729-731); f32+f64 -> f32 (H8)
-    s.score = (float)((double)s.score + (double)st.sum_value);
+    s.score = add_score(s.score, st.sum_value);
     return true;
 }
 
@@ -508,7 +513,7 @@ ML_HD bool step_pre_lite(StepRegs &s, uint32_t action, int reward_kind, uint32_t
     s.board = mv.board;
     s.step += 1;
     s.reward = (float)reward_value(reward_kind, mv.board, prev, st);
-    s.score = (float)((double)s.score + (double)st.sum_value);
+    s.score = add_score(s.score, st.sum_value);
     return true;
 }
 
@@ -551,7 +556,7 @@ ML_HD bool step_pre_lazy(StepRegs &s, uint32_t action, int reward_kind, uint32_t
     s.board = mv.board;
     s.step += 1;
     s.reward = (float)reward_value(reward_kind, mv.board, prev, st);
-    s.score = (float)((double)s.score + (double)st.sum_value);
+    s.score = add_score(s.score, st.sum_value);
     return true;
 }
 

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void k_step_wave(ml2048_state st, int64_t M
         if (lane == 0) {
             reinterpret_cast<uint32_t *>(st.valid)[b] = nv;
             st.step[b] = st.step[b] + 1;
-            st.score[b] = (float)((double)st.score[b] + (double)ms.sum_value);
+            st.score[b] = ml2048::add_score(st.score[b], ms.sum_value);
             st.reward[b] = reward;
             st.terminated[b] = nv == 0u;
             st.invalid[b] = 0;
