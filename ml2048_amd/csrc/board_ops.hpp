@@ -242,16 +242,31 @@ ML_HD MergeStats merge_stats(uint32_t mexp_first, uint32_t mexp_second) {
     return s;
 }
 
+// sum over the bytes n of w with 1 <= n <= 15 of 2^(n+1): the value the merges recorded in w add to the score.
+// Bytes 16 / 17 (H9: the reference's out-of-range buckets) are cleared first; then byte + 31 is, modulo 32, the
+// shift amount n - 1, and 31 for an empty byte - where 4 << 31 drops out of the word - so that each byte costs one
+// SDWA shift (byte operand in, dword out) and no compare/select.  The forward declaration is needed because the
+// helper lives with the spawn code below.
+ML_HD uint32_t shl_byte_by_byte(uint32_t flags, uint32_t amounts, int j);
+ML_HD uint32_t merged_value_sum(uint32_t w) {
+    const uint32_t big = w & 0x10101010u;
+    const uint32_t amounts = (w & ~(big | (big >> 4))) + 0x1F1F1F1Fu;
+    const uint32_t four = 0x04040404u;
+    return (shl_byte_by_byte(four, amounts, 0) + shl_byte_by_byte(four, amounts, 1)) +
+           (shl_byte_by_byte(four, amounts, 2) + shl_byte_by_byte(four, amounts, 3));
+}
+
 // the reward-relevant sums only (no bucket array): what a fused rollout needs every step
 ML_HD void merge_sums(uint32_t mexp_first, uint32_t mexp_second, int kind, uint32_t &sum_value,
                       uint32_t &sum_rank, uint32_t &count) {
-    sum_value = sum_rank = count = 0;
+    sum_value = merged_value_sum(mexp_first) + merged_value_sum(mexp_second);
+    sum_rank = count = 0;
+    if (kind != 2 && kind != 3) return;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const uint32_t word = (k < 4) ? mexp_first : mexp_second;
         const uint32_t num = ubfe(word, 8u * (k & 3), 8);
         const uint32_t ok = (num - 1u) < 15u;
-        sum_value += ok ? (2u << num) : 0u;
         if (kind == 2) sum_rank += ok ? (num + 1u) : 0u;
         if (kind == 3) count += ok;
     }

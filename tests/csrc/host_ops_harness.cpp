@@ -107,6 +107,11 @@ int64_t h_spawn_forms_check(const uint8_t *boards, const uint8_t *perms, const u
     return bad;
 }
 
+// merged_value_sum on n words (bytes 0..17): the SDWA-shift form of "sum of 2^(num+1) over 1 <= num <= 15"
+void h_merged_value_sum(const uint32_t *words, int64_t n, uint32_t *out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = ml2048::merged_value_sum(words[i]);
+}
+
 void h_transpose(const uint8_t *in, uint8_t *out) {
     Board b;
     memcpy(b.r, in, 16);
