@@ -242,24 +242,32 @@ ML_HD MergeStats merge_stats(uint32_t mexp_first, uint32_t mexp_second) {
     return s;
 }
 
-// sum over the bytes n of w with 1 <= n <= 15 of 2^(n+1): the value the merges recorded in w add to the score.
-// Bytes 16 / 17 (H9: the reference's out-of-range buckets) are cleared first; then byte + 31 is, modulo 32, the
-// shift amount n - 1, and 31 for an empty byte - where 4 << 31 drops out of the word - so that each byte costs one
-// SDWA shift (byte operand in, dword out) and no compare/select.  The forward declaration is needed because the
-// helper lives with the spawn code below.
+// sum over the bytes n of (a, b) with 1 <= n <= 15 of 2^(n+1): the value the merges of one move add to the score.
+// byte + 31 is, modulo 32, the shift amount n - 1, and 31 for an empty byte - where 4 << 31 drops out of the word -
+// so each byte costs one SDWA shift (byte operand in, dword out) and no compare/select.  Bytes >= 16 (H9: the
+// reference's out-of-range buckets; tiles of 2^16 and more) take the plain loop, which a wave skips unless one of
+// its boards merges such tiles.  The forward declaration is needed because the helper lives with the spawn code.
 ML_HD uint32_t shl_byte_by_byte(uint32_t flags, uint32_t amounts, int j);
-ML_HD uint32_t merged_value_sum(uint32_t w) {
-    const uint32_t big = w & 0x10101010u;
-    const uint32_t amounts = (w & ~(big | (big >> 4))) + 0x1F1F1F1Fu;
-    const uint32_t four = 0x04040404u;
-    return (shl_byte_by_byte(four, amounts, 0) + shl_byte_by_byte(four, amounts, 1)) +
-           (shl_byte_by_byte(four, amounts, 2) + shl_byte_by_byte(four, amounts, 3));
+ML_HD uint32_t merged_value_sum(uint32_t a, uint32_t b) {
+    if (__builtin_expect(((a | b) & 0xF0F0F0F0u) != 0u, 0)) {
+        uint32_t sum = 0;
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t num = ((k < 4 ? a : b) >> (8 * (k & 3))) & 0xFFu;
+            sum += (num - 1u) < 15u ? (2u << num) : 0u;
+        }
+        return sum;
+    }
+    const uint32_t sa = a + 0x1F1F1F1Fu, sb = b + 0x1F1F1F1Fu, four = 0x04040404u;
+    return ((shl_byte_by_byte(four, sa, 0) + shl_byte_by_byte(four, sa, 1)) +
+            (shl_byte_by_byte(four, sa, 2) + shl_byte_by_byte(four, sa, 3))) +
+           ((shl_byte_by_byte(four, sb, 0) + shl_byte_by_byte(four, sb, 1)) +
+            (shl_byte_by_byte(four, sb, 2) + shl_byte_by_byte(four, sb, 3)));
 }
 
 // the reward-relevant sums only (no bucket array): what a fused rollout needs every step
 ML_HD void merge_sums(uint32_t mexp_first, uint32_t mexp_second, int kind, uint32_t &sum_value,
                       uint32_t &sum_rank, uint32_t &count) {
-    sum_value = merged_value_sum(mexp_first) + merged_value_sum(mexp_second);
+    sum_value = merged_value_sum(mexp_first, mexp_second);
     sum_rank = count = 0;
     if (kind != 2 && kind != 3) return;
 #pragma unroll
@@ -621,13 +629,20 @@ ML_HD U4 philox_at(uint64_t seed, uint64_t counter, uint64_t idx) {
     return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
-// The action sampler's word for call-counter t: word (t & 3) of Philox block (t >> 2) of
-// subsequence idx - i.e. rocRAND's own sequence at offset t (rocrand_init(seed, idx, t)); four
-// consecutive steps share one Philox evaluation in the fused rollout.
-ML_HD uint32_t sampler_word(uint64_t seed, uint64_t t, uint64_t idx) {
-    U4 r = philox_at(seed, t >> 2, idx);
-    const uint32_t k = (uint32_t)(t & 3u);
+// The action sampler's random stream of board idx is rocRAND's Philox4x32-10 sequence W(0), W(1), ... of
+// subsequence idx (W(j) = word j & 3 of Philox block j >> 2, i.e. rocrand_init(seed, idx, j)).
+//   masked-uniform draw of call-counter t: the whole word W(t) (multiply-shift by the number of valid actions);
+//   plain uniform draw (4 actions, 2 bits): bits 2(t & 15).. of W(t >> 4) - sixteen draws per word, so a fused
+//   rollout evaluates Philox once per 64 steps instead of once per 4 (its ten 64-bit multiply rounds were ~6 %
+//   of the rollout kernel).
+// sampler_word returns the word with the draw's bits at the bottom: pick_action takes it from there.
+ML_HD uint32_t philox_seq_word(uint64_t seed, uint64_t j, uint64_t idx) {
+    U4 r = philox_at(seed, j >> 2, idx);
+    const uint32_t k = (uint32_t)(j & 3u);
     return k == 0 ? r.x : k == 1 ? r.y : k == 2 ? r.z : r.w;
+}
+ML_HD uint32_t sampler_word(uint64_t seed, uint64_t t, uint64_t idx, int masked) {
+    return masked ? philox_seq_word(seed, t, idx) : philox_seq_word(seed, t >> 4, idx) >> (2u * (uint32_t)(t & 15u));
 }
 
 // masked-uniform / uniform action from one random word (oracle orc_sample_actions)

@@ -141,17 +141,22 @@ __device__ __forceinline__ void rocrand_words(uint64_t seed, uint64_t counter, u
     w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
 }
 
-// the action sampler's word for call-counter t: rocRAND's sequence of subsequence idx at offset t
-// (= word t&3 of Philox block t>>2; board_ops.hpp sampler_word)
-// (initialised at the block boundary t & ~3 and selected with a wave-uniform compare: starting
+// W(j) of the action sampler's stream (board_ops.hpp sampler_word): rocRAND's sequence of subsequence idx at
+// offset j (= word j&3 of Philox block j>>2)
+// (initialised at the block boundary j & ~3 and selected with a wave-uniform compare: starting
 // rocRAND at a non-multiple-of-4 offset makes its `result[substate]` a runtime-indexed private
 // array, which hipcc promotes to 16 KiB of LDS per workgroup - 17 us instead of 2.4 us per launch)
-__device__ __forceinline__ uint32_t rocrand_sampler_word(uint64_t seed, uint64_t t, uint64_t idx) {
+__device__ __forceinline__ uint32_t rocrand_seq_word(uint64_t seed, uint64_t j, uint64_t idx) {
     rocrand_state_philox4x32_10 s;
-    rocrand_init(seed, idx, t & ~3ull, &s);
+    rocrand_init(seed, idx, j & ~3ull, &s);
     const uint4 v = rocrand4(&s);
-    const uint32_t k = (uint32_t)(t & 3ull); // wave-uniform
+    const uint32_t k = (uint32_t)(j & 3ull); // wave-uniform
     return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
+}
+// the draw of call-counter t, its bits at the bottom of the word: a masked draw takes W(t), a plain uniform
+// draw two bits of W(t >> 4)
+__device__ __forceinline__ uint32_t rocrand_sampler_word(uint64_t seed, uint64_t t, uint64_t idx, int masked) {
+    return masked ? rocrand_seq_word(seed, t, idx) : rocrand_seq_word(seed, t >> 4, idx) >> (2u * (uint32_t)(t & 15ull));
 }
 
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
@@ -656,7 +661,7 @@ __global__ __launch_bounds__(kBlock) void k_sample(const uint8_t *__restrict__ v
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= M) return;
     const uint32_t v = masked ? reinterpret_cast<const uint32_t *>(valid)[i] : 0x01010101u;
-    const uint32_t word = rocrand_sampler_word(seed, counter, (uint64_t)(idx_base + i));
+    const uint32_t word = rocrand_sampler_word(seed, counter, (uint64_t)(idx_base + i), masked);
     uint32_t cnt;
     const uint32_t a = pick_action(v, word, masked, cnt);
     actions[i] = (uint8_t)a;
@@ -881,14 +886,18 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
     // the loop carries the <= 8 merge exponents of the last valid move and expands them lazily.
     uint32_t mexp_first = 0, mexp_second = 0;
     bool merged_stale = false; // true once s.merged no longer reflects (mexp_first, mexp_second)
-    // The sampler's Philox block serves 4 consecutive counters; aw[0] is always the current step's word.
+    // The sampler's stream (board_ops.hpp sampler_word): a masked draw consumes one word W(t), a plain uniform
+    // draw two bits of W(t >> 4).  aw[0] is always the current word; one Philox block serves 4 masked or 64 plain
+    // steps.  `seq_shift` = log2(draws per word).
     uint32_t aw[4];
     {
+        const uint32_t seq_shift = masked ? 0u : 4u;
+        const uint64_t j0 = act_counter0 >> seq_shift;
         rocrand_state_philox4x32_10 rs;
-        rocrand_init(act_seed, (uint64_t)(idx_base + ii), act_counter0 & ~3ull, &rs);
+        rocrand_init(act_seed, (uint64_t)(idx_base + ii), j0 & ~3ull, &rs);
         const uint4 v = rocrand4(&rs);
         aw[0] = v.x; aw[1] = v.y; aw[2] = v.z; aw[3] = v.w;
-        for (uint32_t q = 0; q < (uint32_t)(act_counter0 & 3ull); ++q) { // wave-uniform, outside the loop
+        for (uint32_t q = 0; q < (uint32_t)(j0 & 3ull); ++q) { // wave-uniform, outside the loop
             aw[0] = aw[1]; aw[1] = aw[2]; aw[2] = aw[3];
         }
     }
@@ -988,14 +997,20 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                 }
                 // ---- sample (policy/random.py:17-27)
                 const uint64_t tt = act_counter0 + (uint64_t)t;
-                if (t > 0 && (tt & 3ull) == 0) {
-                    rocrand_state_philox4x32_10 rs;
-                    rocrand_init(act_seed, (uint64_t)(idx_base + ii), tt, &rs);
-                    const uint4 v = rocrand4(&rs);
-                    aw[0] = v.x; aw[1] = v.y; aw[2] = v.z; aw[3] = v.w;
+                const bool plain = LAZY || !masked; // two bits per draw; LAZY instantiations are never masked
+                const uint32_t sub = plain ? (uint32_t)(tt & 15ull) : 0u;
+                if (t > 0 && sub == 0) { // wave-uniform: the next word of the stream
+                    const uint64_t j = plain ? (tt >> 4) : tt;
+                    if ((j & 3ull) == 0) {
+                        rocrand_state_philox4x32_10 rs;
+                        rocrand_init(act_seed, (uint64_t)(idx_base + ii), j, &rs);
+                        const uint4 v = rocrand4(&rs);
+                        aw[0] = v.x; aw[1] = v.y; aw[2] = v.z; aw[3] = v.w;
+                    } else {
+                        aw[0] = aw[1]; aw[1] = aw[2]; aw[2] = aw[3];
+                    }
                 }
-                const uint32_t word = aw[0];
-                aw[0] = aw[1]; aw[1] = aw[2]; aw[2] = aw[3];
+                const uint32_t word = aw[0] >> (2u * sub);
                 uint32_t cnt = 4;
                 const uint32_t action = LAZY ? (word & 3u) : pick_action(s.valid, word, masked, cnt);
                 if (EXTRAS && actions_out && live) actions_out[(int64_t)t * M + i] = (uint8_t)action;

@@ -336,11 +336,14 @@ void orc_sample_actions(const uint8_t *valid, int64_t valid_stride, int64_t M, i
                         float *logp) {
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < M; ++i) {
+        /* The stream of board i is rocRAND's Philox sequence W(0), W(1), ...: W(j) = word (j&3) of block (j>>2).
+           A masked draw uses the whole word W(t); a plain uniform draw the two bits 2(t&15).. of W(t>>4). */
+        const uint64_t j = masked ? counter : (counter >> 4);
         uint32_t blk[4];
-        philox_at(seed, counter >> 2, (uint64_t)(idx_base + i), blk);
-        uint32_t r[1] = {blk[counter & 3u]}; /* word (t&3) of block (t>>2): rocRAND offset t */
+        philox_at(seed, j >> 2, (uint64_t)(idx_base + i), blk);
+        uint32_t r[1] = {blk[j & 3u]};
         if (!masked) {
-            actions[i] = (uint8_t)(r[0] & 3u);
+            actions[i] = (uint8_t)((r[0] >> (2u * (unsigned)(counter & 15u))) & 3u);
             if (logp) logp[i] = neg_log_count(4);
             continue;
         }

@@ -107,9 +107,9 @@ int64_t h_spawn_forms_check(const uint8_t *boards, const uint8_t *perms, const u
     return bad;
 }
 
-// merged_value_sum on n words (bytes 0..17): the SDWA-shift form of "sum of 2^(num+1) over 1 <= num <= 15"
+// merged_value_sum on n word pairs: the SDWA-shift form of "sum of 2^(num+1) over the bytes 1 <= num <= 15"
 void h_merged_value_sum(const uint32_t *words, int64_t n, uint32_t *out) {
-    for (int64_t i = 0; i < n; ++i) out[i] = ml2048::merged_value_sum(words[i]);
+    for (int64_t i = 0; i < n; ++i) out[i] = ml2048::merged_value_sum(words[2 * i], words[2 * i + 1]);
 }
 
 void h_transpose(const uint8_t *in, uint8_t *out) {
@@ -260,7 +260,7 @@ void h_sample(const uint8_t *valid, int64_t M, int64_t idx_base, uint64_t seed, 
         uint32_t v;
         memcpy(&v, valid + 4 * i, 4);
         uint32_t cnt;
-        actions[i] = (uint8_t)pick_action(v, sampler_word(seed, counter, (uint64_t)(idx_base + i)), masked, cnt);
+        actions[i] = (uint8_t)pick_action(v, sampler_word(seed, counter, (uint64_t)(idx_base + i), masked), masked, cnt);
         logp[i] = neg_log_count(cnt);
     }
 }

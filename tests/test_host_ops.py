@@ -106,20 +106,21 @@ def test_move_and_stats_vs_oracle(H, oracle):
 
 
 def test_merged_value_sum_all_byte_values(H):
-    """Every byte value 0..17 in every position, and random words: sum of 2^(num+1) over bytes 1..15
-    (0 = no merge; 16/17 dropped, H9)."""
+    """Every byte value 0..255 in every position, pairs, and random words: sum of 2^(num+1) over the bytes
+    1..15 of a pair of merge-exponent words (0 = no merge; >= 16 dropped, H9)."""
     rng = np.random.default_rng(11)
     cells = np.concatenate([
-        np.array([[v if j == k else 0 for j in range(4)] for k in range(4) for v in range(18)], np.uint8),
-        np.array([[v, w, v, w] for v in range(18) for w in range(18)], np.uint8),
-        rng.integers(0, 18, size=(50000, 4)).astype(np.uint8)])
+        np.array([[v if j == k else 0 for j in range(8)] for k in range(8) for v in range(256)], np.uint8),
+        np.array([[v, w, v, w, w, v, w, v] for v in range(24) for w in range(24)], np.uint8),
+        rng.integers(0, 16, size=(50000, 8)).astype(np.uint8),
+        rng.integers(0, 20, size=(50000, 8)).astype(np.uint8)])
     words = np.ascontiguousarray(cells).view(np.uint32).reshape(-1)
-    out = np.zeros(len(words), np.uint32)
+    out = np.zeros(len(cells), np.uint32)
     H.h_merged_value_sum.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
     H.h_merged_value_sum.restype = None
-    H.h_merged_value_sum(_p(words), len(words), _p(out))
+    H.h_merged_value_sum(_p(words), len(cells), _p(out))
     c = cells.astype(np.int64)
-    want = np.where((c >= 1) & (c <= 15), 2 << c, 0).sum(axis=1)
+    want = np.where((c >= 1) & (c <= 15), 2 << np.minimum(c, 20), 0).sum(axis=1)
     assert np.array_equal(out.astype(np.int64), want)
 
 
