@@ -47,9 +47,8 @@ def build(force: bool = False, verbose: bool = False, extra_hipcc_flags=(), out:
         objs.append(obj)
     for src in SOURCES:
         obj = os.path.splitext(src)[0] + suffix
-        # ML2048_SCHED=max-ilp (A/B only): -1.8 % on the default rollout kernel at C2 (178.7 -> 175.5 us, fewer
-        # s_nop between v_cmp and v_cndmask) but +9..20 % on the trajectory-writing instantiations (more
-        # VGPRs, loads and stores interleaved), and it is a per-file flag - so the compiler's own schedule stays
+        # ML2048_SCHED=<strategy> (A/B only) applies a scheduling strategy to whole files; the default build uses
+        # max-ilp for the plain rollout kernels alone (the extra passes below)
         sched = os.environ.get("ML2048_SCHED", "default")
         sched_flags = [] if sched == "default" else ["-mllvm", f"-amdgpu-sched-strategy={sched}"]
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *sched_flags, *extra_hipcc_flags,
@@ -58,6 +57,19 @@ def build(force: bool = False, verbose: bool = False, extra_hipcc_flags=(), out:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         objs.append(obj)
+        if os.path.basename(src) == "ml2048_hip.hip":
+            # two more passes over the same file: only the plain rollout instantiations and their launcher, once
+            # scheduled with max-ilp (5 % faster at C2) and once with the default strategy (3 % faster at 1 M
+            # boards); see ml2048_plain_launch in the source
+            for tag, flags in (("ilp", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]), ("dflt", [])):
+                obj2 = os.path.splitext(src)[0] + f".plain_{tag}" + suffix
+                cmd2 = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+                        f"-DML2048_ROLLOUT_PLAIN_TU=ml2048_internal_launch_rollout_plain_{tag}", *flags,
+                        *extra_hipcc_flags, "-c", src, "-o", obj2]
+                if verbose:
+                    print(" ".join(cmd2), flush=True)
+                subprocess.check_call(cmd2)
+                objs.append(obj2)
     cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", lib_path, *objs, "-lgomp", "-lpthread"]
     if verbose:
         print(" ".join(cmd), flush=True)

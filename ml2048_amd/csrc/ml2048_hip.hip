@@ -15,11 +15,47 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/ml2048_hip.h"
 #include "board_ops.hpp"
 
 using namespace ml2048;
+
+// The plain (no optional outputs) rollout instantiations are compiled in two further passes over this same file
+// (build.py: -DML2048_ROLLOUT_PLAIN_TU=<launcher name> with and without -mllvm -amdgpu-sched-strategy=max-ilp).
+// Same-box A/B of that scheduling strategy on them: C2 (one wave per SIMD) 105.7 -> 101.0 us - fewer s_nop between
+// v_cmp and v_cndmask, independent chains interleaved; 262 144 boards 249.9 -> 248.6 us; 1 M boards 852 -> 880 us
+// (with several waves per SIMD the hardware interleaves already and the longer live ranges cost); and 9-20 % slower
+// on the trajectory-writing instantiations.  It is a per-file flag, hence the passes; the first pass picks the
+// launcher by the number of boards and instantiates only the EXTRAS kernels itself.
+struct ml2048_plain_launch {
+    dim3 grid, block;
+    hipStream_t stream;
+    hipEvent_t ev_start, ev_stop;
+    ml2048_state st;
+    int64_t M, idx_base;
+    int32_t N;
+    const uint8_t *perm_epochs;
+    const uint32_t *two_masks;
+    const int32_t *schedule;
+    int32_t n_epochs;
+    int masked;
+    uint64_t act_seed, act_counter0;
+    uint64_t *reset_flags;
+    int64_t flag_words;
+    int32_t *last_reset;
+    uint64_t spawn_seed, spawn_counter0, two_threshold;
+    const uint4 *up_src;
+    uint4 *up_dst;
+    int64_t up_n16;
+    unsigned up_blocks;
+    int64_t up_rows;
+};
+__attribute__((visibility("hidden"))) int ml2048_internal_launch_rollout_plain_ilp(int reward_kind, bool fast, bool inv_tables,
+                                                                                   const ml2048_plain_launch &a);
+__attribute__((visibility("hidden"))) int ml2048_internal_launch_rollout_plain_dflt(int reward_kind, bool fast, bool inv_tables,
+                                                                                    const ml2048_plain_launch &a);
 
 namespace {
 
@@ -1383,6 +1419,35 @@ int launch_prepare(hipStream_t s, int64_t M, int64_t idx_base, const ml2048_stat
 
 } // namespace
 
+#ifdef ML2048_ROLLOUT_PLAIN_TU
+int ML2048_ROLLOUT_PLAIN_TU(int reward_kind, bool fast, bool inv_tables, const ml2048_plain_launch &a) {
+    const ml2048_traj traj = {};
+#define ML_PLAIN(K, F, I)                                                                                              \
+    hipExtLaunchKernelGGL((k_rollout<K, F, false, I>), a.grid, a.block, 0, a.stream, a.ev_start, a.ev_stop, 0, a.st, a.M,  \
+                          a.idx_base, a.N, a.perm_epochs, a.two_masks, a.schedule, a.n_epochs, a.masked, a.act_seed,   \
+                          a.act_counter0, (uint8_t *)nullptr, (uint64_t *)nullptr, a.reset_flags, a.flag_words,        \
+                          a.last_reset, a.spawn_seed, a.spawn_counter0, a.two_threshold, traj, a.up_src, a.up_dst,     \
+                          a.up_n16, a.up_blocks, a.up_rows)
+#define ML_PLAIN_KIND(K)                 \
+    if (fast) {                          \
+        ML_PLAIN(K, true, false);        \
+    } else if (inv_tables) {             \
+        ML_PLAIN(K, false, true);        \
+    } else {                             \
+        ML_PLAIN(K, false, false);       \
+    }
+    switch (reward_kind) {
+    case ML2048_REWARD_NORMAL: ML_PLAIN_KIND(REWARD_NORMAL); break;
+    case ML2048_REWARD_IMPROVED: ML_PLAIN_KIND(REWARD_IMPROVED); break;
+    case ML2048_REWARD_RANK: ML_PLAIN_KIND(REWARD_RANK); break;
+    case ML2048_REWARD_MAXCELL: ML_PLAIN_KIND(REWARD_MAXCELL); break;
+    default: return ML2048_E_INVALID;
+    }
+#undef ML_PLAIN_KIND
+#undef ML_PLAIN
+    return 0;
+}
+#else
 // ================================================================================================
 extern "C" {
 
@@ -1594,6 +1659,16 @@ void ml2048_timer_destroy(void *timer) {
     delete t;
 }
 
+// largest M that runs the max-ilp build of the plain rollout kernels (see ml2048_plain_launch); ML2048_PLAIN_ILP_MAX
+// overrides it for A/B runs
+static int64_t plain_ilp_max_boards() {
+    static const int64_t v = [] {
+        const char *e = getenv("ML2048_PLAIN_ILP_MAX");
+        return e ? (int64_t)atoll(e) : (int64_t)131072;
+    }();
+    return v;
+}
+
 static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
                           const uint8_t *perm_epochs, const uint32_t *two_masks, const int32_t *schedule, int32_t n_epochs,
                           int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0, uint8_t *actions_out,
@@ -1626,25 +1701,31 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
     hipEvent_t ev_start = timer ? timer->start : nullptr, ev_stop = timer ? timer->stop : nullptr;
     if (timer) timer->used = true;
     if (inv_tables && (fast || extras)) return fail(ML2048_E_UNSUPPORTED, "expanded tables: plain table-mode rollouts only");
-#define ML_LAUNCH2(K, F, X, I)                                                                               \
-    hipExtLaunchKernelGGL((k_rollout<K, F, X, I>), grid, block, 0, s, ev_start, ev_stop, 0, *st, M, idx_base, N, perm_epochs, two_masks, \
+    if (!extras) { // the plain instantiations live in their own compilation passes (see ml2048_plain_launch)
+        ml2048_plain_launch a;
+        a.grid = grid, a.block = block, a.stream = s, a.ev_start = ev_start, a.ev_stop = ev_stop;
+        a.st = *st, a.M = M, a.idx_base = idx_base, a.N = N;
+        a.perm_epochs = perm_epochs, a.two_masks = two_masks, a.schedule = schedule, a.n_epochs = n_epochs;
+        a.masked = masked, a.act_seed = act_seed, a.act_counter0 = act_counter0;
+        a.reset_flags = reset_flags, a.flag_words = W, a.last_reset = last_reset;
+        a.spawn_seed = spawn_seed, a.spawn_counter0 = spawn_counter0, a.two_threshold = thr;
+        a.up_src = (const uint4 *)up_src, a.up_dst = (uint4 *)up_dst, a.up_n16 = up_n16, a.up_blocks = up_blocks, a.up_rows = up_rows;
+        if (M <= plain_ilp_max_boards() ? ml2048_internal_launch_rollout_plain_ilp(reward_kind, fast, inv_tables, a)
+                                    : ml2048_internal_launch_rollout_plain_dflt(reward_kind, fast, inv_tables, a))
+            return fail(ML2048_E_INVALID, "reward_kind=%d", reward_kind);
+        return check_launch("ml2048_rollout");
+    }
+#define ML_LAUNCH2(K, F)                                                                                     \
+    hipExtLaunchKernelGGL((k_rollout<K, F, true, false>), grid, block, 0, s, ev_start, ev_stop, 0, *st, M, idx_base, N, perm_epochs, two_masks, \
                        schedule, n_epochs, masked, act_seed, act_counter0, actions_out, digests_out,         \
                        reset_flags, W,                                                                       \
                        last_reset, spawn_seed, spawn_counter0, thr, traj, (const uint4 *)up_src, (uint4 *)up_dst, up_n16, up_blocks, up_rows)
-#define ML_LAUNCH(K, F)                 \
-    if (extras) {                       \
-        ML_LAUNCH2(K, F, true, false);  \
-    } else if (!F && inv_tables) {      \
-        ML_LAUNCH2(K, false, false, true); \
-    } else {                            \
-        ML_LAUNCH2(K, F, false, false); \
-    }
 #define ML_KIND(F)                                                                   \
     switch (reward_kind) {                                                           \
-    case ML2048_REWARD_NORMAL: ML_LAUNCH(REWARD_NORMAL, F); break;                   \
-    case ML2048_REWARD_IMPROVED: ML_LAUNCH(REWARD_IMPROVED, F); break;               \
-    case ML2048_REWARD_RANK: ML_LAUNCH(REWARD_RANK, F); break;                       \
-    case ML2048_REWARD_MAXCELL: ML_LAUNCH(REWARD_MAXCELL, F); break;                 \
+    case ML2048_REWARD_NORMAL: ML_LAUNCH2(REWARD_NORMAL, F); break;                  \
+    case ML2048_REWARD_IMPROVED: ML_LAUNCH2(REWARD_IMPROVED, F); break;              \
+    case ML2048_REWARD_RANK: ML_LAUNCH2(REWARD_RANK, F); break;                      \
+    case ML2048_REWARD_MAXCELL: ML_LAUNCH2(REWARD_MAXCELL, F); break;                \
     default: return fail(ML2048_E_INVALID, "reward_kind=%d", reward_kind);           \
     }
     if (fast) {
@@ -1653,7 +1734,6 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
         ML_KIND(false)
     }
 #undef ML_KIND
-#undef ML_LAUNCH
 #undef ML_LAUNCH2
     return check_launch("ml2048_rollout");
 }
@@ -1784,3 +1864,4 @@ int ml2048_gae(void *stream, int64_t U, int64_t S, int64_t G, const float *v0, c
 }
 
 } // extern "C"
+#endif // ML2048_ROLLOUT_PLAIN_TU
