@@ -707,8 +707,6 @@ class VecGame:
                 _lib.check(L.ml2048_devrng_schedule(*args), "devrng_schedule")
             else:
                 _lib.check(L.ml2048_devrng2_schedule(*args, int(expanded)), "devrng2_schedule")
-        if os.environ.get("ML2048_DEBUG_SYNC_SCHED"):
-            side.synchronize()
         ready = torch.cuda.Event()
         ready.record(side)
         main.wait_event(ready)
