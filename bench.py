@@ -193,7 +193,7 @@ def main():
     if "ML2048_HOST_THREADS" not in os.environ:
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
         share = max(1, host_cpu_share() // max(1, local_world))
-        os.environ["ML2048_HOST_THREADS"] = str(max(1, min(10, share - 4)))
+        os.environ["ML2048_HOST_THREADS"] = str(max(1, min(8, share - 4)))
 
     M, N, K, W = args.boards, args.env_steps, args.steps, args.warmup
     # shard `rank` of a 2-level game: independent replica with its own seed (SURVEY 8e replica mode)

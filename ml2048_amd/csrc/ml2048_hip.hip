@@ -77,6 +77,10 @@ int check_launch(const char *what) {
 
 constexpr int kBlock = 256;      // threads per workgroup for the per-board kernels (4 waves)
 constexpr int kFlagChunk = 128;  // rollout steps whose re-deal flags are parked in LDS between flushes
+#ifndef ML2048_STEP_UNROLL
+#define ML2048_STEP_UNROLL 8
+#endif
+constexpr int kStepUnroll = ML2048_STEP_UNROLL; // steps per iteration of the plain rollout loop (A/B: -DML2048_STEP_UNROLL=n)
 constexpr int kPrepBlock = 1024; // boards per workgroup in the prepare scan
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -985,7 +989,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
         constexpr bool LAZY = decltype(lazy_tag)::value;
         for (int t0 = 0; t0 < N; t0 += kFlagChunk) {
             const int t1 = t0 + kFlagChunk < N ? t0 + kFlagChunk : N;
-            for (int t = t0; t < t1; ++t) {
+            auto one_step = [&](const int t) __attribute__((always_inline)) {
                 // table mode: the pre-drawn host schedule; fast mode: rocRAND Philox words keyed
                 // (spawn_seed; board; 2*(counter0+t) for the deal, +1 for the step) as the per-step API does
                 uint32_t two_mask = n_two_mask;
@@ -1095,7 +1099,19 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                     h = wave_sum_u64(h);
                     if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(digests_out + t), (unsigned long long)h);
                 }
+            };
+            // kStepUnroll steps per loop iteration: the registers that carry the prefetched table rows and the board
+            // from one step to the next are renamed instead of copied at every step boundary (the compiler does not
+            // unroll this loop by itself: it contains convergent operations and has a run-time trip count)
+            constexpr int U = EXTRAS ? 1 : kStepUnroll;
+            int t = t0;
+            if constexpr (U > 1) {
+                for (; t + U <= t1; t += U) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) one_step(t + u);
+                }
             }
+            for (; t < t1; ++t) one_step(t);
             // flush this chunk's re-deal flags (wave-private LDS row: a wave-scope fence is enough)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
