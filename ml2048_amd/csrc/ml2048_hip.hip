@@ -76,7 +76,13 @@ int check_launch(const char *what) {
 }
 
 constexpr int kBlock = 256;      // threads per workgroup for the per-board kernels (4 waves)
-constexpr int kFlagChunk = 128;  // rollout steps whose re-deal flags are parked in LDS between flushes
+// rollout steps whose re-deal flags are parked between flushes: in LDS (128 steps), or - ML2048_PARK_IN_VGPR, the
+// small-M pass of the plain kernels - in a register pair, one step per lane (64 steps)
+#ifdef ML2048_PARK_IN_VGPR
+constexpr int kFlagChunk = 64;
+#else
+constexpr int kFlagChunk = 128;
+#endif
 #ifndef ML2048_STEP_UNROLL
 #define ML2048_STEP_UNROLL 8
 #endif
@@ -197,6 +203,19 @@ __device__ __forceinline__ uint32_t rocrand_seq_word(uint64_t seed, uint64_t j, 
 // draw two bits of W(t >> 4)
 __device__ __forceinline__ uint32_t rocrand_sampler_word(uint64_t seed, uint64_t t, uint64_t idx, int masked) {
     return masked ? rocrand_seq_word(seed, t, idx) : rocrand_seq_word(seed, t >> 4, idx) >> (2u * (uint32_t)(t & 15ull));
+}
+
+// lane `lane` (wave-uniform) of the pair (lo, hi) replaced by the wave-uniform 64-bit `value`: two v_writelane_b32
+// (one scalar operand per VALU instruction on gfx9: the lane select goes through m0)
+__device__ __forceinline__ void write_lane64(uint32_t &lo, uint32_t &hi, unsigned long long value, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+        : "+v"(lo), "+v"(hi)
+        : "s"((uint32_t)value), "s"((uint32_t)(value >> 32)), "s"(lane)
+        : "m0");
+#else
+    (void)lo, (void)hi, (void)value, (void)lane;
+#endif
 }
 
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
@@ -884,9 +903,17 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                                                     uint64_t spawn_counter0, uint64_t thr, ml2048_traj traj,
                                                     const uint4 *__restrict__ up_src, uint4 *__restrict__ up_dst,
                                                     int64_t up_n16, unsigned up_blocks, int64_t up_rows) {
-    // re-deal flags of up to kFlagChunk steps are parked in LDS so that the step loop holds no global
-    // store (its acknowledgement would share the vmcnt queue with the prefetched loads)
+    // The re-deal flags (one 64-bit ballot per step) of up to kFlagChunk steps are parked so that the step loop holds
+    // no global store (its acknowledgement would share the vmcnt queue with the prefetched loads): in LDS, or - the
+    // pass for small M, where a lone wave per SIMD pays for every slot - in a VGPR pair, step q of the chunk in lane q,
+    // written with v_writelane.  The LDS write shares lgkmcnt with the scalar loads of the schedule and its lane-0
+    // store needs an exec-mask round trip: 3.7 us of the 95.7 us kernel at C2; the register form costs 1.6 us less
+    // there and 1 % more at 1 M boards (two more VALU per step where other waves hid the LDS write anyway).
+#ifdef ML2048_PARK_IN_VGPR
+    uint32_t park_lo = 0, park_hi = 0;
+#else
     __shared__ unsigned long long flag_park[kBlock / 64][kFlagChunk];
+#endif
     // The schedule kernel of the NEXT rollout (csrc/devrng.hip) may share a CU with one of these
     // workgroups; the rollout is the critical path, so its waves win the issue arbitration.
     __builtin_amdgcn_s_setprio(1);
@@ -1017,7 +1044,11 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                 // ---- prepare (game_numba.py:619-658)
                 const bool deal = s.terminated != 0;
                 const unsigned long long dealt = __ballot(deal && live);
+#ifdef ML2048_PARK_IN_VGPR
+                write_lane64(park_lo, park_hi, dealt, t - t0);
+#else
                 if (lane == 0) flag_park[threadIdx.x >> 6][t - t0] = dealt;
+#endif
                 if (deal) {
                     clear_regs(s);
                     invalid = 0;
@@ -1112,12 +1143,18 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                 }
             }
             for (; t < t1; ++t) one_step(t);
+#ifdef ML2048_PARK_IN_VGPR
+            // flush this chunk's re-deal flags: lane q holds step t0 + q
+            if (lane < t1 - t0)
+                reset_flags[(int64_t)(t0 + lane) * flag_words + wave_global] = (uint64_t)park_lo | ((uint64_t)park_hi << 32);
+#else
             // flush this chunk's re-deal flags (wave-private LDS row: a wave-scope fence is enough)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             for (int q = lane; q < t1 - t0; q += 64)
                 reset_flags[(int64_t)(t0 + q) * flag_words + wave_global] = flag_park[threadIdx.x >> 6][q];
+#endif
         }
     };
     if constexpr (EXTRAS) {
