@@ -62,7 +62,7 @@ def build(force: bool = False, verbose: bool = False, extra_hipcc_flags=(), out:
             # scheduled with max-ilp (5 % faster at C2) and once with the default strategy (3 % faster at 1 M
             # boards); see ml2048_plain_launch in the source
             ilp = os.environ.get("ML2048_SCHED_PLAIN", "max-ilp")  # A/B: another strategy for the small-M pass
-            for tag, flags in (("ilp", ["-mllvm", f"-amdgpu-sched-strategy={ilp}", "-DML2048_PARK_IN_VGPR=1"]), ("dflt", [])):
+            for tag, flags in (("ilp", ["-mllvm", f"-amdgpu-sched-strategy={ilp}", "-DML2048_LONE_WAVE=1"]), ("dflt", [])):
                 obj2 = os.path.splitext(src)[0] + f".plain_{tag}" + suffix
                 cmd2 = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                         f"-DML2048_ROLLOUT_PLAIN_TU=ml2048_internal_launch_rollout_plain_{tag}", *flags,

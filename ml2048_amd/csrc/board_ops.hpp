@@ -20,6 +20,16 @@
 
 namespace ml2048 {
 
+// "does any lane of this wavefront see `cond`" on the device (a wave-uniform answer: the caller's branch is a scalar
+// branch with no exec-mask bookkeeping); the condition itself on the host
+ML_HD bool any_lane(bool cond) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(cond) != 0ull;
+#else
+    return cond;
+#endif
+}
+
 struct Board {
     uint32_t r[4];
 };
@@ -245,11 +255,11 @@ ML_HD MergeStats merge_stats(uint32_t mexp_first, uint32_t mexp_second) {
 // sum over the bytes n of (a, b) with 1 <= n <= 15 of 2^(n+1): the value the merges of one move add to the score.
 // byte + 31 is, modulo 32, the shift amount n - 1, and 31 for an empty byte - where 4 << 31 drops out of the word -
 // so each byte costs one SDWA shift (byte operand in, dword out) and no compare/select.  Bytes >= 16 (H9: the
-// reference's out-of-range buckets; tiles of 2^16 and more) take the plain loop, which a wave skips unless one of
-// its boards merges such tiles.  The forward declaration is needed because the helper lives with the spawn code.
+// reference's out-of-range buckets; tiles of 2^16 and more) take the plain loop - the whole wave does, when one of
+// its boards merges such tiles, so that the test is a scalar branch.  The forward declaration is needed because the helper lives with the spawn code.
 ML_HD uint32_t shl_byte_by_byte(uint32_t flags, uint32_t amounts, int j);
 ML_HD uint32_t merged_value_sum(uint32_t a, uint32_t b) {
-    if (__builtin_expect(((a | b) & 0xF0F0F0F0u) != 0u, 0)) {
+    if (__builtin_expect(any_lane(((a | b) & 0xF0F0F0F0u) != 0u), 0)) { // rare, and taken by the whole wave
         uint32_t sum = 0;
         for (int k = 0; k < 8; ++k) {
             const uint32_t num = ((k < 4 ? a : b) >> (8 * (k & 3))) & 0xFFu;
@@ -393,13 +403,19 @@ ML_HD void spawn_table_inv(Board &b, const uint32_t perm[4], const uint32_t inv[
         for (int j = 0; j < 4; ++j) acc |= shl_byte_by_byte(z, inv[k], j);
     }
     const uint32_t hits = acc >> 7;
+    // A full board (hits == 0: cannot follow a valid move) is left alone.  ML2048_LONE_WAVE (the compilation pass for
+    // small M, one wave per SIMD): by OR-ing a zero tile in - two selects instead of a divergent branch, whose
+    // exec-mask bookkeeping costs a lone wave more (-1.7 % together with the scalar branch in merged_value_sum);
+    // otherwise by the branch, which is 1.4 % cheaper at 1 M boards where VALU issue is the limit.
+#ifndef ML2048_LONE_WAVE
     if (hits == 0) return;
-    const uint32_t i = (uint32_t)__builtin_ctz(hits);
+#endif
+    const uint32_t i = hits ? (uint32_t)__builtin_ctz(hits) : 0u;
     const uint64_t plo = (uint64_t)perm[0] | ((uint64_t)perm[1] << 32);
     const uint64_t phi = (uint64_t)perm[2] | ((uint64_t)perm[3] << 32);
     const uint64_t half = (i & 8u) ? phi : plo;
     const uint32_t c = (uint32_t)(half >> (8u * (i & 7u))) & 0xFu;
-    set_cell(b, c, 2u - ubfe(two_mask, c, 1));
+    set_cell(b, c, hits ? 2u - ubfe(two_mask, c, 1) : 0u);
 }
 
 // inverse of one permutation row, in board layout (what the schedule upload computes per row)

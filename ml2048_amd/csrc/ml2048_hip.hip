@@ -76,9 +76,9 @@ int check_launch(const char *what) {
 }
 
 constexpr int kBlock = 256;      // threads per workgroup for the per-board kernels (4 waves)
-// rollout steps whose re-deal flags are parked between flushes: in LDS (128 steps), or - ML2048_PARK_IN_VGPR, the
+// rollout steps whose re-deal flags are parked between flushes: in LDS (128 steps), or - ML2048_LONE_WAVE, the
 // small-M pass of the plain kernels - in a register pair, one step per lane (64 steps)
-#ifdef ML2048_PARK_IN_VGPR
+#ifdef ML2048_LONE_WAVE
 constexpr int kFlagChunk = 64;
 #else
 constexpr int kFlagChunk = 128;
@@ -909,7 +909,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
     // written with v_writelane.  The LDS write shares lgkmcnt with the scalar loads of the schedule and its lane-0
     // store needs an exec-mask round trip: 3.7 us of the 95.7 us kernel at C2; the register form costs 1.6 us less
     // there and 1 % more at 1 M boards (two more VALU per step where other waves hid the LDS write anyway).
-#ifdef ML2048_PARK_IN_VGPR
+#ifdef ML2048_LONE_WAVE
     uint32_t park_lo = 0, park_hi = 0;
 #else
     __shared__ unsigned long long flag_park[kBlock / 64][kFlagChunk];
@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                 // ---- prepare (game_numba.py:619-658)
                 const bool deal = s.terminated != 0;
                 const unsigned long long dealt = __ballot(deal && live);
-#ifdef ML2048_PARK_IN_VGPR
+#ifdef ML2048_LONE_WAVE
                 write_lane64(park_lo, park_hi, dealt, t - t0);
 #else
                 if (lane == 0) flag_park[threadIdx.x >> 6][t - t0] = dealt;
@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                 }
             }
             for (; t < t1; ++t) one_step(t);
-#ifdef ML2048_PARK_IN_VGPR
+#ifdef ML2048_LONE_WAVE
             // flush this chunk's re-deal flags: lane q holds step t0 + q
             if (lane < t1 - t0)
                 reset_flags[(int64_t)(t0 + lane) * flag_words + wave_global] = (uint64_t)park_lo | ((uint64_t)park_hi << 32);
