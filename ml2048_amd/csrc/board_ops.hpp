@@ -566,7 +566,14 @@ ML_HD bool step_pre_lite(StepRegs &s, uint32_t action, int reward_kind, uint32_t
 ML_HD bool valid_consistent(const Board &b, uint32_t valid) { return valid_actions(b) == valid; }
 
 ML_HD bool board_differs(const Board &a, const Board &b) {
-    return ((a.r[0] ^ b.r[0]) | (a.r[1] ^ b.r[1]) | (a.r[2] ^ b.r[2]) | (a.r[3] ^ b.r[3])) != 0u;
+    uint32_t d = (a.r[0] ^ b.r[0]) | (a.r[1] ^ b.r[1]) | (a.r[2] ^ b.r[2]) | (a.r[3] ^ b.r[3]);
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ML2048_LONE_WAVE)
+    // keep it one value and one compare: the compiler otherwise tests the four words separately and joins the
+    // results with scalar ORs (4 v_cmp + 3 s_or instead of 3-4 VALU + 1 v_cmp) - cheaper when other waves fill the
+    // scalar slots (1 M boards: +1.4 % with the barrier), dearer for a lone wave
+    asm("" : "+v"(d));
+#endif
+    return d != 0u;
 }
 
 // == (valid_actions(b) == 0) for every board with at least one tile

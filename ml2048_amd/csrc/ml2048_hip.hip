@@ -1016,6 +1016,23 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
         constexpr bool LAZY = decltype(lazy_tag)::value;
         for (int t0 = 0; t0 < N; t0 += kFlagChunk) {
             const int t1 = t0 + kFlagChunk < N ? t0 + kFlagChunk : N;
+#ifdef ML2048_LONE_WAVE
+            // The schedule of this chunk, one entry per lane (lane q: the entry step t0 + q fetches ahead, i.e.
+            // step t0 + q + 1's): epoch as a byte offset into the tables, the two row bases, the epoch's two-mask.
+            // The step loop broadcasts them with v_readlane - four VALU slots instead of ~16 scalar address
+            // instructions, three scalar loads and their lgkmcnt waits per step, which a lone wave pays in full.
+            uint32_t sch_eo = 0, sch_rp = 0, sch_rs = 0, sch_tm = 0;
+            const uint32_t row_lane = (uint32_t)(idx_base + ii); // only its low 10 bits matter
+            if (!FAST && VPF) {
+                const int j = t0 + lane + 1 < N ? t0 + lane + 1 : N - 1;
+                const uint32_t e = (uint32_t)schedule[3 * j + 0];
+                const uint32_t ec = e < e_last ? e : e_last;
+                sch_eo = ec * (uint32_t)kEpochBytes;
+                sch_rp = (uint32_t)schedule[3 * j + 1];
+                sch_rs = (uint32_t)schedule[3 * j + 2];
+                sch_tm = two_masks[ec];
+            }
+#endif
             auto one_step = [&](const int t) __attribute__((always_inline)) {
                 // table mode: the pre-drawn host schedule; fast mode: rocRAND Philox words keyed
                 // (spawn_seed; board; 2*(counter0+t) for the deal, +1 for the step) as the per-step API does
@@ -1023,6 +1040,27 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                 uint32_t perm_p = n_perm_p;
                 uint32_t perm_s[4] = {n_perm_s[0], n_perm_s[1], n_perm_s[2], n_perm_s[3]};
                 uint32_t inv_s[4] = {n_inv_s[0], n_inv_s[1], n_inv_s[2], n_inv_s[3]};
+#ifdef ML2048_LONE_WAVE
+                if (!FAST && VPF) {
+                    // requests for step t+1 from the chunk's lane-held schedule (lane q = entry t0 + q + 1)
+                    const int q = t - t0;
+                    const uint32_t s_eo = (uint32_t)__builtin_amdgcn_readlane((int)sch_eo, q);
+                    const uint32_t s_rp = (uint32_t)__builtin_amdgcn_readlane((int)sch_rp, q);
+                    const uint32_t s_rs = (uint32_t)__builtin_amdgcn_readlane((int)sch_rs, q);
+                    n_two_mask = (uint32_t)__builtin_amdgcn_readlane((int)sch_tm, q);
+                    constexpr uint32_t kRowBytes = INV ? 32u : 16u;
+                    const uint32_t off_p = ((s_rp + row_lane) & (uint32_t)(ML2048_RAND_SIZE - 1)) * kRowBytes + s_eo;
+                    const uint32_t off_s = ((s_rs + row_lane) & (uint32_t)(ML2048_RAND_SIZE - 1)) * kRowBytes + s_eo;
+                    n_perm_p = *reinterpret_cast<const uint32_t *>(perm_epochs + off_p);
+                    const uint4 *row = reinterpret_cast<const uint4 *>(perm_epochs + off_s);
+                    const uint4 v = row[0];
+                    n_perm_s[0] = v.x; n_perm_s[1] = v.y; n_perm_s[2] = v.z; n_perm_s[3] = v.w;
+                    if (INV) {
+                        const uint4 w = row[1];
+                        n_inv_s[0] = w.x; n_inv_s[1] = w.y; n_inv_s[2] = w.z; n_inv_s[3] = w.w;
+                    }
+                } else
+#endif
                 if (!FAST) {
                     const uint8_t *tab1 = perm_epochs + (int64_t)e1 * kEpochBytes;
                     if (VPF) { // requests for step t+1, consumed one iteration later
