@@ -394,7 +394,8 @@ ML_HD uint32_t shl_byte_by_byte(uint32_t flags, uint32_t amounts, int j) {
 
 // one tile (the step's spawn, count = 1); equals spawn_table(b, perm, two_mask, 1) when inv is the
 // inverse of perm
-ML_HD void spawn_table_inv(Board &b, const uint32_t perm[4], const uint32_t inv[4], uint32_t two_mask) {
+// returns the emptiness mask before the spawn (bit i <=> the cell at position i of the row was empty)
+ML_HD uint32_t spawn_table_inv(Board &b, const uint32_t perm[4], const uint32_t inv[4], uint32_t two_mask) {
     uint32_t acc = 0; // bit 7 + i  <=>  the cell at position i of the row is empty
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -408,7 +409,7 @@ ML_HD void spawn_table_inv(Board &b, const uint32_t perm[4], const uint32_t inv[
     // exec-mask bookkeeping costs a lone wave more (-1.7 % together with the scalar branch in merged_value_sum);
     // otherwise by the branch, which is 1.4 % cheaper at 1 M boards where VALU issue is the limit.
 #ifndef ML2048_LONE_WAVE
-    if (hits == 0) return;
+    if (hits == 0) return 0u;
 #endif
     const uint32_t i = hits ? (uint32_t)__builtin_ctz(hits) : 0u;
     const uint64_t plo = (uint64_t)perm[0] | ((uint64_t)perm[1] << 32);
@@ -416,6 +417,7 @@ ML_HD void spawn_table_inv(Board &b, const uint32_t perm[4], const uint32_t inv[
     const uint64_t half = (i & 8u) ? phi : plo;
     const uint32_t c = (uint32_t)(half >> (8u * (i & 7u))) & 0xFu;
     set_cell(b, c, hits ? 2u - ubfe(two_mask, c, 1) : 0u);
+    return hits;
 }
 
 // inverse of one permutation row, in board layout (what the schedule upload computes per row)
@@ -607,6 +609,19 @@ ML_HD bool step_pre_lazy(StepRegs &s, uint32_t action, int reward_kind, uint32_t
 }
 
 ML_HD void step_post_lazy(StepRegs &s) { s.terminated = no_move_left(s.board); }
+
+// the same when the spawn reported which cells were empty before it (spawn_table_inv): the board is full now exactly
+// when one cell was empty then, which replaces the zero test over all 16 cells
+ML_HD void step_post_lazy(StepRegs &s, uint32_t empties_before_spawn) {
+    const Board &b = s.board;
+    uint32_t eq = 0; // 0x80 wherever two neighbours hold the same byte (only meaningful on a full board)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) eq |= z_bytes(b.r[i] ^ (b.r[i] >> 8)) & 0x00808080u;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) eq |= z_bytes(b.r[i] ^ b.r[i + 1]);
+    const bool full = (empties_before_spawn & (empties_before_spawn - 1u)) == 0u;
+    s.terminated = (full && eq == 0u) ? 1u : 0u;
+}
 
 ML_HD void step_post(StepRegs &s) {
     s.valid = valid_actions(s.board);

@@ -1129,15 +1129,18 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                 if (LAZY ? step_pre_lazy(s, action, KIND, mexp_first, mexp_second)
                          : step_pre_lite(s, action, KIND, mexp_first, mexp_second)) {
                     merged_stale = true;
+                    uint32_t empties = 0;
                     if (FAST) {
                         uint32_t w4[4];
                         rocrand_words(spawn_seed, 2ull * (spawn_counter0 + (uint64_t)t) + 1ull, (uint64_t)(idx_base + ii), w4);
                         spawn_counter(s.board, w4[0], w4[1], thr);
                     } else {
-                        if (INV) spawn_table_inv(s.board, perm_s, inv_s, two_mask);
+                        if (INV) empties = spawn_table_inv(s.board, perm_s, inv_s, two_mask);
                         else spawn_table(s.board, perm_s, two_mask, 1);
                     }
-                    if (LAZY) step_post_lazy(s); else step_post(s);
+                    if (LAZY && INV && !FAST) step_post_lazy(s, empties);
+                    else if (LAZY) step_post_lazy(s);
+                    else step_post(s);
                     invalid = 0;
                 } else {
                     invalid = 1;

@@ -100,9 +100,18 @@ int64_t h_spawn_forms_check(const uint8_t *boards, const uint8_t *perms, const u
             const uint32_t pos = (inv[c >> 2] >> (8 * (c & 3))) & 0xFF;
             if (((perm[pos >> 2] >> (8 * (pos & 3))) & 0xFF) != (uint32_t)c) ++bad;
         }
+        bool had_empty = false;
+        for (int c = 0; c < 16; ++c) had_empty |= ((b.r[c >> 2] >> (8 * (c & 3))) & 0xFF) == 0;
         spawn_table(a, perm, two_masks[i], 1);
-        spawn_table_inv(b, perm, inv, two_masks[i]);
+        const uint32_t empties = spawn_table_inv(b, perm, inv, two_masks[i]);
         if (memcmp(a.r, b.r, 16) != 0) ++bad;
+        if (had_empty) { // "terminated" from the spawn's emptiness mask == the full test on the board after the spawn
+            StepRegs s1 = {}, s2 = {};
+            s1.board = b, s2.board = b;
+            step_post_lazy(s1);
+            step_post_lazy(s2, empties);
+            if (s1.terminated != s2.terminated) ++bad;
+        }
     }
     return bad;
 }
