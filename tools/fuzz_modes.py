@@ -17,7 +17,11 @@ rng = np.random.default_rng(2048)
 kinds = ["normal", "improved", "rank", "maxcell"]
 t0 = time.time()
 rounds = ops = 0
+last_report = t0
 while time.time() - t0 < budget:
+    if time.time() - last_report > 60:  # a line a minute: a silent run looks hung to the job runner
+        last_report = time.time()
+        print(f"... {rounds} rounds, {ops} operations after {last_report - t0:.0f}s", flush=True)
     kind = kinds[rounds % 4]
     envs = {m: amd.VecGame(M, kind, schedule=m) for m in ("host", "host-async", "device")}
     step_env = amd.VecGame(M, kind)
