@@ -63,9 +63,11 @@ def parse():
                          "rehearsing the N>1 launch contract on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: map every rank to cuda:0 (needs --dist-backend gloo)")
-    ap.add_argument("--schedule", choices=["host", "host-async", "device"], default="host-async",
+    ap.add_argument("--schedule", choices=["auto", "host", "host-async", "device"], default="auto",
                     help="where the bit-exact mode's PCG64 draw schedule is computed: host (synchronous native call), "
-                         "host-async (native producer thread drawing ahead; default), device (csrc/devrng.hip)")
+                         "host-async (pipelined native producer threads drawing ahead), device (csrc/devrng2.hip: no host "
+                         "threads); auto (default) = host-async when this rank's CPU share allows at least 6 producer "
+                         "workers, else device")
     ap.add_argument("--prefetch", type=int, default=0,
                     help="draw the next rollout's host schedule on a worker thread (default 0: the async kernel "
                          "launch already overlaps the host schedule of rollout k+1 with the GPU running rollout k)")
@@ -194,6 +196,10 @@ def main():
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
         share = max(1, host_cpu_share() // max(1, local_world))
         os.environ["ML2048_HOST_THREADS"] = str(max(1, min(8, share - 4)))
+    if args.schedule == "auto":
+        # the host stream needs ~6 workers to stay ahead of the 0.09 ms rollout kernel (4 workers: 0.149 ms per
+        # rollout; measured); on a rank with fewer CPUs the schedule drawn on the GPU (0.128 ms, no host threads) wins
+        args.schedule = "host-async" if int(os.environ["ML2048_HOST_THREADS"]) >= 6 else "device"
 
     M, N, K, W = args.boards, args.env_steps, args.steps, args.warmup
     # shard `rank` of a 2-level game: independent replica with its own seed (SURVEY 8e replica mode)
