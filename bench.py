@@ -332,7 +332,7 @@ def main():
         d1 = time.perf_counter() - t1
         extras["stepwise"] = {"value": M * N * reps / d1, "unit": "board-steps/s",
                               "us_per_env_step": d1 / (N * reps) * 1e6,
-                              "note": "per-step API: 5 kernel launches per env step (prepare x3, sample, step)"}
+                              "note": "per-step API: 3 kernel launches per env step (prepare, sample, step); host-launch-bound"}
 
     if rank == 0 and world == 1 and args.mode == "fused" and not args.no_extras:
         # secondary: the same fused workload in rocRAND spawn mode (no host PCG64 schedule; statistically the same
