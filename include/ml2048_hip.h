@@ -393,21 +393,104 @@ int ml2048_encoder_front(void *stream, int64_t N, const uint8_t *board, const fl
                          float negative_slope, float *out_full, float *out_rows, float *out_cols);
 
 /*
+ * ---- one env step of a policy-driven loop as ONE launch -----------------------------------------------------
+ *
+ * The reference's driver alternates  prepare() -> observations() -> policy -> step()
+ * (VecRunner.step_once, src/ml2048/runner.py:74-109).  Between step(t) and prepare(t+1) there is only host code
+ * whose PCG64 draws do not depend on game state (step draws integers(0,1024), game_numba.py:670; prepare
+ * draws random(), possibly the tables, and integers(0,1024), :622-626), so ml2048_step_prepare runs
+ *     step(t)   [game_numba.py:660-738]   then   prepare(t+1)   [:619-658]
+ * in one kernel, and can also emit what the next policy call consumes.  After it returns (stream order) the env is
+ * in the state the reference has after prepare(t+1): finished games re-dealt with ids in ascending slot order,
+ * *n_reset / reset_indices as ml2048_prepare yields them, prev_board / prev_valid as step(t) left them.
+ *
+ * ml2048_step_out: what step(t) RETURNED - the reference's VecStepResult views (:685-698) as they read between
+ * step() and the next prepare(), which clobbers them for finished games.  Dense [M] arrays with the reference's
+ * dtypes; every pointer may be NULL (skipped).  Pointing them at the [game] slices of the trainer's replay buffers
+ * replaces Trainer.on_stepped's copies (run_train3.py:125-155; uint8 0/1 is what torch.bool stores, uint8 boards
+ * are REPLAY_SPEC's int8 bytes).  `id` is the record's id before any re-deal (replay.py:147-151 reads it per slot).
+ */
+typedef struct ml2048_step_out {
+    uint8_t *state;              /* [M][16]  board after move + spawn                      result["state"] */
+    uint8_t *valid_actions;      /* [M][4]                                                 result["valid_actions"] */
+    uint8_t *merged;             /* [M][16]  stale on an invalid move (H3)                 result["merged"] */
+    int32_t *step;               /* [M]      stale on an invalid move                      result["step"] */
+    float *reward;               /* [M]      stale on an invalid move                      result["reward"] */
+    float *score;                /* [M]                                                    result["score"] */
+    uint8_t *terminated;         /* [M]                                                    result["terminated"] */
+    uint8_t *invalid;            /* [M]                                                    result["invalid"] */
+    int32_t *id;                 /* [M]      _data["id"] as of step(t)                                  */
+    uint8_t *prev_state;         /* [M][16]  copy of st.prev_board                         result["prev_state"] */
+    uint8_t *prev_valid_actions; /* [M][4]   copy of st.prev_valid                         result["prev_valid_actions"] */
+} ml2048_step_out;
+
+/*
+ *   actions / action_dtype / reward_kind / two_prob / idx_base        as ml2048_step
+ *   randperm_step, randfloat_step, row_base_step                      step(t)'s tables and rand_step + rand_offset (:670,:681)
+ *   randperm_prepare, randfloat_prepare, row_base_prepare             prepare(t+1)'s (:622-626, :651): other buffers than
+ *                                                                     the step's when that prepare regenerated the tables
+ *   randperm_step == NULL selects the rocRAND spawn mode: spawn_seed with spawn_counter_step / spawn_counter_prepare
+ *                                                                     as ml2048_step_fast / ml2048_prepare_fast take them
+ *   game_count, n_reset, reset_indices (may be NULL)                  as ml2048_prepare
+ *   scratch            ml2048_step_prepare_scratch_bytes() bytes of device memory, 8-byte aligned, ZEROED ONCE by the
+ *                      caller and then owned by this env (epoch-tagged status words + the epoch itself, advanced on
+ *                      the device: the launch may be captured in a hipGraph and replayed)
+ *   onehot             optional float32[M][16][4][4] observation of the post-prepare boards (_network.py:91-95,105)
+ *   board_i64          optional int64[M][16] of the same boards (_network.py:87-88)
+ *   next_actions       optional uint8[M]: RandomPolicy's draw for step t+1 on the post-prepare masks
+ *   next_logp          optional float32[M] log-probabilities of those draws (needs next_actions)
+ *   act_seed, act_counter, act_masked                                 as ml2048_sample_actions
+ *   hist_counts        optional int32[20]: += max-tile histogram of the games this step finished (runner.py:120-136)
+ * Plain struct, passed by pointer and copied at the call: ctypes callers keep one instance and update a few fields.
+ */
+typedef struct ml2048_step_prepare_args {
+    int64_t M, idx_base;
+    ml2048_state st;
+    const void *actions;
+    int32_t action_dtype, reward_kind;
+    double two_prob;
+    const uint8_t *randperm_step;
+    const float *randfloat_step;
+    int64_t row_base_step;
+    const uint8_t *randperm_prepare;
+    const float *randfloat_prepare;
+    int64_t row_base_prepare;
+    uint64_t spawn_seed, spawn_counter_step, spawn_counter_prepare;
+    int32_t *game_count;
+    int32_t *n_reset;
+    int64_t *reset_indices;
+    void *scratch;
+    ml2048_step_out out;
+    float *onehot;
+    int64_t *board_i64;
+    uint8_t *next_actions;
+    float *next_logp;
+    uint64_t act_seed, act_counter;
+    int32_t act_masked, reserved;
+    int32_t *hist_counts;
+} ml2048_step_prepare_args;
+int64_t ml2048_step_prepare_scratch_bytes(void);
+int ml2048_step_prepare(void *stream, const ml2048_step_prepare_args *args);
+
+/*
  * Episode statistics of the FIRST `rounds` games - the evaluation loop of eval_perf.py:64-102 with
  * ReplayRecorder (src/ml2048/replay.py:110-232) as its collector, on device.  Call once after every
  * ml2048_step (per-step API).  Per slot, age[] counts the steps its current game has lived (what the
  * recorder's buffer.steps counts, replay.py:167: every step, valid move or not); a new id in the slot
- * restarts the count; in the step that terminates a game with id < rounds the kernel adds
+ * restarts the count; in the step that terminates a game with id_base <= id < id_base + rounds the kernel adds
  * (1, age, final score) to entry [max tile exponent] of count / step_sum / score_sum (eval_perf.py:88-99;
  * scores are integer-valued, so the integer sum equals the reference's float sum).
  *   age, seen_id    device int32[M], 16-byte aligned (as st->id; st->terminated 4-byte aligned); initialise age
  *                   to 0 and seen_id to INT32_MIN (or any id never used)
  *   count, step_sum, score_sum   device uint64[18], zero-initialised by the caller; index = max exponent
+ *   id_base         the env's game counter when the evaluation started (VecGame._game_count survives reset(),
+ *                   game_numba.py:582 vs :606, so the "first N games" of an evaluation are ids id_base..id_base+N-1;
+ *                   0 for a freshly constructed env, which is the only case eval_perf.py has)
  * The evaluation is complete when sum(count) == rounds ("the first N games, not the first N terminated
  * games", README.md:112-118).
  */
 int ml2048_episode_stats(void *stream, int64_t M, const ml2048_state *st, int32_t *age, int32_t *seen_id,
-                         int32_t rounds, uint64_t *count, uint64_t *step_sum, uint64_t *score_sum);
+                         int32_t id_base, int32_t rounds, uint64_t *count, uint64_t *step_sum, uint64_t *score_sum);
 
 /*
  * ---- rollout consumers (SURVEY 8f "next" rows) ------------------------------------------------

@@ -32,6 +32,28 @@ class Traj(C.Structure):
                                            "next_state", "next_valid_actions", "step", "terminated")]
 
 
+class StepOut(C.Structure):
+    """struct ml2048_step_out (include/ml2048_hip.h)."""
+
+    _fields_ = [(n, C.c_void_p) for n in ("state", "valid_actions", "merged", "step", "reward", "score", "terminated",
+                                           "invalid", "id", "prev_state", "prev_valid_actions")]
+
+
+class StepPrepareArgs(C.Structure):
+    """struct ml2048_step_prepare_args (include/ml2048_hip.h)."""
+
+    _fields_ = [("M", C.c_int64), ("idx_base", C.c_int64), ("st", State), ("actions", C.c_void_p),
+                ("action_dtype", C.c_int32), ("reward_kind", C.c_int32), ("two_prob", C.c_double),
+                ("randperm_step", C.c_void_p), ("randfloat_step", C.c_void_p), ("row_base_step", C.c_int64),
+                ("randperm_prepare", C.c_void_p), ("randfloat_prepare", C.c_void_p), ("row_base_prepare", C.c_int64),
+                ("spawn_seed", C.c_uint64), ("spawn_counter_step", C.c_uint64), ("spawn_counter_prepare", C.c_uint64),
+                ("game_count", C.c_void_p), ("n_reset", C.c_void_p), ("reset_indices", C.c_void_p),
+                ("scratch", C.c_void_p), ("out", StepOut), ("onehot", C.c_void_p), ("board_i64", C.c_void_p),
+                ("next_actions", C.c_void_p), ("next_logp", C.c_void_p), ("act_seed", C.c_uint64),
+                ("act_counter", C.c_uint64), ("act_masked", C.c_int32), ("reserved", C.c_int32),
+                ("hist_counts", C.c_void_p)]
+
+
 class Pcg64State(C.Structure):
     """struct ml2048_pcg64 (include/ml2048_hip.h)."""
 
@@ -51,6 +73,8 @@ _SIGNATURES = {
                                  C.c_double, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ml2048_step": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_void_p, C.c_int, C.c_int,
                               C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ml2048_step_prepare_scratch_bytes": (C.c_int64, []),
+    "ml2048_step_prepare": (C.c_int, [C.c_void_p, C.POINTER(StepPrepareArgs)]),
     "ml2048_step_wave": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_void_p, C.c_int, C.c_int,
                                    C.c_double, C.c_int64, C.c_void_p, C.c_void_p]),
     "ml2048_prepare_fast": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_double, C.c_uint64,
@@ -99,7 +123,7 @@ _SIGNATURES = {
     "ml2048_encoder_front": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ml2048_episode_stats": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(State), C.c_void_p, C.c_void_p, C.c_int32,
-                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+                                       C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ml2048_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
     "ml2048_rollout": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_int32, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64,

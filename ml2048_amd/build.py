@@ -9,10 +9,11 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libml2048_hip.so")
-SOURCES = [os.path.join(CSRC, "ml2048_hip.hip"), os.path.join(CSRC, "devrng.hip"), os.path.join(CSRC, "devrng2.hip"),
-           os.path.join(CSRC, "encoder.hip")]
+SOURCES = [os.path.join(CSRC, "ml2048_hip.hip"), os.path.join(CSRC, "step_prepare.hip"), os.path.join(CSRC, "devrng.hip"),
+           os.path.join(CSRC, "devrng2.hip"), os.path.join(CSRC, "encoder.hip")]
 HOST_SOURCES = [os.path.join(CSRC, "hostrng.cpp")]  # plain host C++ (no device code)
-HEADERS = [os.path.join(CSRC, "board_ops.hpp"), os.path.join(_HERE, "..", "include", "ml2048_hip.h")]
+HEADERS = [os.path.join(CSRC, "board_ops.hpp"), os.path.join(CSRC, "device_helpers.hpp"),
+           os.path.join(_HERE, "..", "include", "ml2048_hip.h")]
 
 
 def hipcc() -> str:

@@ -1,0 +1,133 @@
+// device_helpers.hpp - small device-side helpers shared by the kernel files of libml2048_hip.so
+// (ml2048_hip.hip, step_prepare.hip): 16-byte board loads/stores, the action loader, the spawn-table row loaders,
+// the rocRAND Philox words of the sampler / the counter-based spawn, wave reductions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocrand/rocrand_kernel.h>
+#include <stdint.h>
+
+#include "../../include/ml2048_hip.h"
+#include "board_ops.hpp"
+
+namespace ml2048 {
+namespace dev {
+
+__device__ __forceinline__ Board load_board(const uint8_t *base, int64_t i) {
+    uint4 v = reinterpret_cast<const uint4 *>(base)[i];
+    Board b;
+    b.r[0] = v.x; b.r[1] = v.y; b.r[2] = v.z; b.r[3] = v.w;
+    return b;
+}
+
+__device__ __forceinline__ void store16(uint8_t *base, int64_t i, const uint32_t w[4]) {
+    reinterpret_cast<uint4 *>(base)[i] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ uint32_t load_action(const void *actions, int dtype, int64_t i) {
+    if (dtype == ML2048_ACT_U8) return reinterpret_cast<const uint8_t *>(actions)[i];
+    if (dtype == ML2048_ACT_I32) return (uint32_t) reinterpret_cast<const int32_t *>(actions)[i];
+    int64_t a = reinterpret_cast<const int64_t *>(actions)[i];
+    return (a < 0 || a > 3) ? 0xFFFFFFFFu : (uint32_t)a;
+}
+
+// bit c <=> float64(randfloat[c]) < two_prob for the 16 cells (game_numba.py:207; H1, H2)
+__device__ __forceinline__ uint32_t two_mask_from_table(const float *randfloat, double two_prob) {
+    const int lane = threadIdx.x & 63;
+    float f = randfloat[lane & 15];
+    unsigned long long m = __ballot((double)f < two_prob);
+    return (uint32_t)(m & 0xFFFFull);
+}
+
+__device__ __forceinline__ void load_perm_row(const uint8_t *randperm, int64_t row, uint32_t perm[4]) {
+    uint4 v = reinterpret_cast<const uint4 *>(randperm)[row & (ML2048_RAND_SIZE - 1)];
+    perm[0] = v.x; perm[1] = v.y; perm[2] = v.z; perm[3] = v.w;
+}
+
+// first four cells of a permutation row (the re-deal reads two: board_ops.hpp deal_table)
+__device__ __forceinline__ uint32_t load_perm_head(const uint8_t *randperm, int64_t row) {
+    return reinterpret_cast<const uint32_t *>(randperm)[(row & (ML2048_RAND_SIZE - 1)) * 4];
+}
+
+// INV tables: a row is 32 bytes - the permutation, then its inverse in board layout (board_ops.hpp
+// spawn_table_inv); ROW16 = uint4 units per row
+template <bool INV>
+__device__ __forceinline__ void load_table_row(const uint8_t *tab, int64_t row, uint32_t perm[4], uint32_t inv[4]) {
+    const uint4 *t = reinterpret_cast<const uint4 *>(tab);
+    const int64_t r = row & (ML2048_RAND_SIZE - 1);
+    if (INV) {
+        const uint4 v = t[2 * r], w = t[2 * r + 1];
+        perm[0] = v.x; perm[1] = v.y; perm[2] = v.z; perm[3] = v.w;
+        inv[0] = w.x; inv[1] = w.y; inv[2] = w.z; inv[3] = w.w;
+    } else {
+        const uint4 v = t[r];
+        perm[0] = v.x; perm[1] = v.y; perm[2] = v.z; perm[3] = v.w;
+    }
+}
+template <bool INV>
+__device__ __forceinline__ uint32_t load_table_head(const uint8_t *tab, int64_t row) {
+    return reinterpret_cast<const uint32_t *>(tab)[(row & (ML2048_RAND_SIZE - 1)) * (INV ? 8 : 4)];
+}
+
+// One 16-byte unit of a schedule upload.  The first `rows` units of the source are permutation rows:
+// each goes out as 32 bytes (the row, then its inverse); the rest (schedule, masks) is copied behind them.
+__device__ __forceinline__ void upload_unit(uint4 *dst, const uint4 *src, int64_t j, int64_t rows) {
+    const uint4 v = src[j];
+    if (j < rows) {
+        const uint32_t perm[4] = {v.x, v.y, v.z, v.w};
+        uint32_t inv[4];
+        invert_perm_row(perm, inv);
+        dst[2 * j] = v;
+        dst[2 * j + 1] = make_uint4(inv[0], inv[1], inv[2], inv[3]);
+    } else {
+        dst[j + rows] = v;
+    }
+}
+
+// rocRAND Philox4x32-10 device generator: words of (seed, subsequence = idx, offset = 4*counter)
+__device__ __forceinline__ void rocrand_words(uint64_t seed, uint64_t counter, uint64_t idx, uint32_t w[4]) {
+    rocrand_state_philox4x32_10 s;
+    rocrand_init(seed, idx, counter * 4ull, &s);
+    uint4 v = rocrand4(&s);
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+}
+
+// W(j) of the action sampler's stream (board_ops.hpp sampler_word): rocRAND's sequence of subsequence idx at
+// offset j (= word j&3 of Philox block j>>2)
+// (initialised at the block boundary j & ~3 and selected with a wave-uniform compare: starting
+// rocRAND at a non-multiple-of-4 offset makes its `result[substate]` a runtime-indexed private
+// array, which hipcc promotes to 16 KiB of LDS per workgroup - 17 us instead of 2.4 us per launch)
+__device__ __forceinline__ uint32_t rocrand_seq_word(uint64_t seed, uint64_t j, uint64_t idx) {
+    rocrand_state_philox4x32_10 s;
+    rocrand_init(seed, idx, j & ~3ull, &s);
+    const uint4 v = rocrand4(&s);
+    const uint32_t k = (uint32_t)(j & 3ull); // wave-uniform
+    return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
+}
+// the draw of call-counter t, its bits at the bottom of the word: a masked draw takes W(t), a plain uniform
+// draw two bits of W(t >> 4)
+__device__ __forceinline__ uint32_t rocrand_sampler_word(uint64_t seed, uint64_t t, uint64_t idx, int masked) {
+    return masked ? rocrand_seq_word(seed, t, idx) : rocrand_seq_word(seed, t >> 4, idx) >> (2u * (uint32_t)(t & 15ull));
+}
+
+// lane `lane` (wave-uniform) of the pair (lo, hi) replaced by the wave-uniform 64-bit `value`: two v_writelane_b32
+// (one scalar operand per VALU instruction on gfx9: the lane select goes through m0)
+__device__ __forceinline__ void write_lane64(uint32_t &lo, uint32_t &hi, unsigned long long value, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+        : "+v"(lo), "+v"(hi)
+        : "s"((uint32_t)value), "s"((uint32_t)(value >> 32)), "s"(lane)
+        : "m0");
+#else
+    (void)lo, (void)hi, (void)value, (void)lane;
+#endif
+}
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v; // lane 0 holds the sum
+}
+
+
+} // namespace dev
+} // namespace ml2048

@@ -366,7 +366,11 @@ __global__ __launch_bounds__(256) void k2_rows(Layout l) {
     // NOT unrolled on purpose: the fully unrolled form (constant shifts) of this 64-bit xor-swap chain gave wrong
     // rows in part of one wavefront, only while other kernels shared the GPU (the swap targets and the input rows
     // were verified correct, the non-unrolled loop never fails: tools/debug/fuzz_device2.py); cause not isolated
+#ifdef ML2048_K2_ROWS_UNROLL // A/B build of the unrolled form (tools/debug/fuzz_device2.py)
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
     for (uint32_t i2 = 15; i2 >= 1; --i2) {
         const uint32_t j = (uint32_t)(js >> (4 * i2)) & 15u;
         const uint64_t hi_i = i2 >= 8u ? row_hi : row_lo, hi_j = j >= 8u ? row_hi : row_lo;
@@ -504,8 +508,15 @@ struct GraphEntry {
     GraphKey key;
     hipGraphExec_t exec;
     uint64_t last_use;
+    hipStream_t last_stream; // where the exec was launched last: drained before the exec is destroyed
 };
+// One env keeps 3 output slots x 2 table layouts alive per rollout length; with fewer entries than that times the
+// number of live envs every call recaptured (and destroyed an exec that could still be executing).
+#ifdef ML2048_GRAPH_CACHE_R1 // A/B only: round 1's cache (8 entries, evicted execs destroyed without draining)
 constexpr size_t kGraphCache = 8;
+#else
+constexpr size_t kGraphCache = 96;
+#endif
 static std::mutex g_graph_mu;
 static std::vector<GraphEntry> g_graphs;
 static uint64_t g_graph_clock = 0;
@@ -536,6 +547,7 @@ int ml2048_devrng2_schedule(void *stream, void *workspace, ml2048_devrng *rng, u
         for (GraphEntry &g : g_graphs)
             if (g.key == key) {
                 g.last_use = ++g_graph_clock;
+                g.last_stream = s;
                 return (int)hipGraphLaunch(g.exec, s);
             }
         if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -552,10 +564,17 @@ int ml2048_devrng2_schedule(void *stream, void *workspace, ml2048_devrng *rng, u
                     size_t oldest = 0;
                     for (size_t i = 1; i < g_graphs.size(); ++i)
                         if (g_graphs[i].last_use < g_graphs[oldest].last_use) oldest = i;
+                    // An exec owns the kernel-argument memory of its nodes: destroying one that is still executing
+                    // lets a later instantiation reuse that memory under waves that have not read their arguments
+                    // yet.  Its last stream is drained first (rare: only when the cache is full).
+#ifndef ML2048_GRAPH_CACHE_R1
+                    (void)hipStreamSynchronize(g_graphs[oldest].last_stream);
+                    (void)hipGetLastError();
+#endif
                     (void)hipGraphExecDestroy(g_graphs[oldest].exec);
                     g_graphs.erase(g_graphs.begin() + (long)oldest);
                 }
-                g_graphs.push_back(GraphEntry{key, exec, ++g_graph_clock});
+                g_graphs.push_back(GraphEntry{key, exec, ++g_graph_clock, s});
                 return (int)hipGraphLaunch(exec, s);
             }
             (void)hipGetLastError(); // capture or instantiation refused: fall through to the direct launches

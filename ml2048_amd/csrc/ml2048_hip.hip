@@ -19,8 +19,10 @@
 
 #include "../../include/ml2048_hip.h"
 #include "board_ops.hpp"
+#include "device_helpers.hpp"
 
 using namespace ml2048;
+using namespace ml2048::dev;
 
 // The plain (no optional outputs) rollout instantiations are compiled in two further passes over this same file
 // (build.py: -DML2048_ROLLOUT_PLAIN_TU=<launcher name> with and without -mllvm -amdgpu-sched-strategy=max-ilp).
@@ -105,123 +107,6 @@ int check_state(int64_t M, const ml2048_state *st) {
         if ((uintptr_t)p[i] % al[i]) return fail(ML2048_E_ALIGN, "state.%s must be %u-byte aligned", n[i], al[i]);
     }
     return 0;
-}
-
-// ---- device helpers --------------------------------------------------------------------------
-__device__ __forceinline__ Board load_board(const uint8_t *base, int64_t i) {
-    uint4 v = reinterpret_cast<const uint4 *>(base)[i];
-    Board b;
-    b.r[0] = v.x; b.r[1] = v.y; b.r[2] = v.z; b.r[3] = v.w;
-    return b;
-}
-
-__device__ __forceinline__ void store16(uint8_t *base, int64_t i, const uint32_t w[4]) {
-    reinterpret_cast<uint4 *>(base)[i] = make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-__device__ __forceinline__ uint32_t load_action(const void *actions, int dtype, int64_t i) {
-    if (dtype == ML2048_ACT_U8) return reinterpret_cast<const uint8_t *>(actions)[i];
-    if (dtype == ML2048_ACT_I32) return (uint32_t) reinterpret_cast<const int32_t *>(actions)[i];
-    int64_t a = reinterpret_cast<const int64_t *>(actions)[i];
-    return (a < 0 || a > 3) ? 0xFFFFFFFFu : (uint32_t)a;
-}
-
-// bit c <=> float64(randfloat[c]) < two_prob for the 16 cells (game_numba.py:207; H1, H2)
-__device__ __forceinline__ uint32_t two_mask_from_table(const float *randfloat, double two_prob) {
-    const int lane = threadIdx.x & 63;
-    float f = randfloat[lane & 15];
-    unsigned long long m = __ballot((double)f < two_prob);
-    return (uint32_t)(m & 0xFFFFull);
-}
-
-__device__ __forceinline__ void load_perm_row(const uint8_t *randperm, int64_t row, uint32_t perm[4]) {
-    uint4 v = reinterpret_cast<const uint4 *>(randperm)[row & (ML2048_RAND_SIZE - 1)];
-    perm[0] = v.x; perm[1] = v.y; perm[2] = v.z; perm[3] = v.w;
-}
-
-// first four cells of a permutation row (the re-deal reads two: board_ops.hpp deal_table)
-__device__ __forceinline__ uint32_t load_perm_head(const uint8_t *randperm, int64_t row) {
-    return reinterpret_cast<const uint32_t *>(randperm)[(row & (ML2048_RAND_SIZE - 1)) * 4];
-}
-
-// INV tables: a row is 32 bytes - the permutation, then its inverse in board layout (board_ops.hpp
-// spawn_table_inv); ROW16 = uint4 units per row
-template <bool INV>
-__device__ __forceinline__ void load_table_row(const uint8_t *tab, int64_t row, uint32_t perm[4], uint32_t inv[4]) {
-    const uint4 *t = reinterpret_cast<const uint4 *>(tab);
-    const int64_t r = row & (ML2048_RAND_SIZE - 1);
-    if (INV) {
-        const uint4 v = t[2 * r], w = t[2 * r + 1];
-        perm[0] = v.x; perm[1] = v.y; perm[2] = v.z; perm[3] = v.w;
-        inv[0] = w.x; inv[1] = w.y; inv[2] = w.z; inv[3] = w.w;
-    } else {
-        const uint4 v = t[r];
-        perm[0] = v.x; perm[1] = v.y; perm[2] = v.z; perm[3] = v.w;
-    }
-}
-template <bool INV>
-__device__ __forceinline__ uint32_t load_table_head(const uint8_t *tab, int64_t row) {
-    return reinterpret_cast<const uint32_t *>(tab)[(row & (ML2048_RAND_SIZE - 1)) * (INV ? 8 : 4)];
-}
-
-// One 16-byte unit of a schedule upload.  The first `rows` units of the source are permutation rows:
-// each goes out as 32 bytes (the row, then its inverse); the rest (schedule, masks) is copied behind them.
-__device__ __forceinline__ void upload_unit(uint4 *dst, const uint4 *src, int64_t j, int64_t rows) {
-    const uint4 v = src[j];
-    if (j < rows) {
-        const uint32_t perm[4] = {v.x, v.y, v.z, v.w};
-        uint32_t inv[4];
-        invert_perm_row(perm, inv);
-        dst[2 * j] = v;
-        dst[2 * j + 1] = make_uint4(inv[0], inv[1], inv[2], inv[3]);
-    } else {
-        dst[j + rows] = v;
-    }
-}
-
-// rocRAND Philox4x32-10 device generator: words of (seed, subsequence = idx, offset = 4*counter)
-__device__ __forceinline__ void rocrand_words(uint64_t seed, uint64_t counter, uint64_t idx, uint32_t w[4]) {
-    rocrand_state_philox4x32_10 s;
-    rocrand_init(seed, idx, counter * 4ull, &s);
-    uint4 v = rocrand4(&s);
-    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-}
-
-// W(j) of the action sampler's stream (board_ops.hpp sampler_word): rocRAND's sequence of subsequence idx at
-// offset j (= word j&3 of Philox block j>>2)
-// (initialised at the block boundary j & ~3 and selected with a wave-uniform compare: starting
-// rocRAND at a non-multiple-of-4 offset makes its `result[substate]` a runtime-indexed private
-// array, which hipcc promotes to 16 KiB of LDS per workgroup - 17 us instead of 2.4 us per launch)
-__device__ __forceinline__ uint32_t rocrand_seq_word(uint64_t seed, uint64_t j, uint64_t idx) {
-    rocrand_state_philox4x32_10 s;
-    rocrand_init(seed, idx, j & ~3ull, &s);
-    const uint4 v = rocrand4(&s);
-    const uint32_t k = (uint32_t)(j & 3ull); // wave-uniform
-    return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
-}
-// the draw of call-counter t, its bits at the bottom of the word: a masked draw takes W(t), a plain uniform
-// draw two bits of W(t >> 4)
-__device__ __forceinline__ uint32_t rocrand_sampler_word(uint64_t seed, uint64_t t, uint64_t idx, int masked) {
-    return masked ? rocrand_seq_word(seed, t, idx) : rocrand_seq_word(seed, t >> 4, idx) >> (2u * (uint32_t)(t & 15ull));
-}
-
-// lane `lane` (wave-uniform) of the pair (lo, hi) replaced by the wave-uniform 64-bit `value`: two v_writelane_b32
-// (one scalar operand per VALU instruction on gfx9: the lane select goes through m0)
-__device__ __forceinline__ void write_lane64(uint32_t &lo, uint32_t &hi, unsigned long long value, int lane) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
-        : "+v"(lo), "+v"(hi)
-        : "s"((uint32_t)value), "s"((uint32_t)(value >> 32)), "s"(lane)
-        : "m0");
-#else
-    (void)lo, (void)hi, (void)value, (void)lane;
-#endif
-}
-
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v; // lane 0 holds the sum
 }
 
 // ---- reset -------------------------------------------------------------------------------------
@@ -1344,7 +1229,7 @@ __global__ __launch_bounds__(kBlock) void k_ids_assign(ml2048_state st, int64_t 
 // the slot restarts it), and a game is folded into the table in the step that terminates it.
 constexpr int kStatsBlock = 1024;
 __global__ __launch_bounds__(kStatsBlock) void k_episode_stats(ml2048_state st, int64_t M, int32_t *__restrict__ age,
-                                                          int32_t *__restrict__ seen_id, int32_t rounds,
+                                                          int32_t *__restrict__ seen_id, int32_t id_base, int32_t rounds,
                                                           unsigned long long *__restrict__ count,
                                                           unsigned long long *__restrict__ step_sum,
                                                           unsigned long long *__restrict__ score_sum) {
@@ -1364,7 +1249,7 @@ __global__ __launch_bounds__(kStatsBlock) void k_episode_stats(ml2048_state st, 
         if (a >= 0) { // a < 0: already folded in, waiting for its re-deal
             a += 1;
             if (term) {
-                if (id >= 0 && id < rounds) {
+                if ((uint32_t)(id - id_base) < (uint32_t)rounds) { // id_base <= id < id_base + rounds
                     const Board b = load_board(st.board, i);
                     const uint32_t mc = max_cell(b);
                     atomicAdd(&acc[0][mc], 1ull);
@@ -1543,6 +1428,17 @@ int ML2048_ROLLOUT_PLAIN_TU(int reward_kind, bool fast, bool inv_tables, const m
 }
 #else
 // ================================================================================================
+// shared with the other kernel files of the library (step_prepare.hip): one error buffer, one set of state checks
+__attribute__((visibility("hidden"))) int ml2048_internal_fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+__attribute__((visibility("hidden"))) int ml2048_internal_check_state(int64_t M, const ml2048_state *st) { return check_state(M, st); }
+__attribute__((visibility("hidden"))) uint64_t ml2048_internal_two_threshold(double two_prob) { return two_threshold(two_prob); }
+
 extern "C" {
 
 int ml2048_abi_version(void) { return ML2048_ABI_VERSION; }
@@ -1915,7 +1811,7 @@ int ml2048_rollout_finish_ids(void *stream, int64_t M, const ml2048_state *st, i
 }
 
 int ml2048_episode_stats(void *stream, int64_t M, const ml2048_state *st, int32_t *age, int32_t *seen_id,
-                         int32_t rounds, uint64_t *count, uint64_t *step_sum, uint64_t *score_sum) {
+                         int32_t id_base, int32_t rounds, uint64_t *count, uint64_t *step_sum, uint64_t *score_sum) {
     if (int rc = check_state(M, st)) return rc;
     if (!age || !seen_id || !count || !step_sum || !score_sum) return fail(ML2048_E_INVALID, "age/seen_id/count/step_sum/score_sum is NULL");
     if (rounds < 0) return fail(ML2048_E_INVALID, "rounds=%d", rounds);
@@ -1925,7 +1821,7 @@ int ml2048_episode_stats(void *stream, int64_t M, const ml2048_state *st, int32_
     if (blocks < 1) blocks = 1;
     if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(k_episode_stats, dim3((unsigned)blocks), dim3(kStatsBlock), 0, (hipStream_t)stream, *st, M, age,
-                       seen_id, rounds, (unsigned long long *)count, (unsigned long long *)step_sum,
+                       seen_id, id_base, rounds, (unsigned long long *)count, (unsigned long long *)step_sum,
                        (unsigned long long *)score_sum);
     return check_launch("ml2048_episode_stats");
 }

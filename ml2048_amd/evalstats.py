@@ -20,12 +20,16 @@ from .game import VecGame
 
 class EpisodeStats:
     """Register `on_stepped` as a `VecRunner.EVENT_STEPPED` callback (or call it after every
-    `env.step*`), starting with a freshly reset env; `completed()` == rounds ends the evaluation."""
+    `env.step*`), starting with a freshly constructed or freshly reset env; `completed()` == rounds ends the
+    evaluation.  "The first `rounds` games" are counted from the env's game counter at construction of this
+    object: `_game_count` survives `reset()` (game_numba.py:582 vs :606), so a re-used env deals ids that
+    start above zero."""
 
     def __init__(self, env: VecGame, rounds: int):
         if rounds <= 0:
             raise ValueError(f"rounds={rounds}")
         self.env, self.rounds = env, int(rounds)
+        self.id_base = int(env._game_count)
         dev, M = env.device, env._size
         self._age = torch.zeros((M,), dtype=torch.int32, device=dev)
         self._seen = torch.full((M,), -(2**31), dtype=torch.int32, device=dev)
@@ -35,7 +39,7 @@ class EpisodeStats:
         env = self.env
         with env._dev_ctx():
             _lib.check(env._L.ml2048_episode_stats(
-                env._stream(), env._size, env._st(), self._age.data_ptr(), self._seen.data_ptr(), self.rounds,
+                env._stream(), env._size, env._st(), self._age.data_ptr(), self._seen.data_ptr(), self.id_base, self.rounds,
                 self._acc[0].data_ptr(), self._acc[1].data_ptr(), self._acc[2].data_ptr()), "episode_stats")
 
     def completed(self) -> int:

@@ -2,6 +2,8 @@
 (src/ml2048/policy/__init__.py:10-19): (state, valid_actions) -> (actions long, log_probs float)."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -30,7 +32,9 @@ class RandomPolicy(Policy):
 
     def __init__(self, seed: int | None = None, *, masked: bool = True, idx_base: int = 0):
         self._L = _lib.load()
-        self.seed = int(torch.seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+        # an unseeded policy draws its own seed; torch's global generators are left alone (the reference seeds a
+        # private torch.Generator, policy/random.py:12-15), so a caller's torch.manual_seed() stays in force
+        self.seed = int(int.from_bytes(os.urandom(8), "little") if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
         self.masked = masked
         self.counter = 0
         self.idx_base = idx_base

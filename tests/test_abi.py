@@ -65,9 +65,9 @@ def test_argument_validation_without_gpu(lib):
                                     None, None, 0, 0) == -1
     assert lib.ml2048_rollout_chain(None, 64, 0, C.byref(ok), 8, 4096, 4096, 1, 4096, 0, 0, 0, 0, 4096, 4096,
                                     8192, None, 64, 0) == -1              # next_dst missing
-    assert lib.ml2048_episode_stats(None, 64, C.byref(ok), None, None, 10, None, None, None) == -1
-    assert lib.ml2048_episode_stats(None, 64, C.byref(ok), 4096, 4096, -1, 4096, 4096, 4096) == -1
-    assert lib.ml2048_episode_stats(None, 64, C.byref(ok), 4100, 4096, 5, 4096, 4096, 4096) == -2   # age alignment
+    assert lib.ml2048_episode_stats(None, 64, C.byref(ok), None, None, 0, 10, None, None, None) == -1
+    assert lib.ml2048_episode_stats(None, 64, C.byref(ok), 4096, 4096, 0, -1, 4096, 4096, 4096) == -1
+    assert lib.ml2048_episode_stats(None, 64, C.byref(ok), 4100, 4096, 0, 5, 4096, 4096, 4096) == -2   # age alignment
     assert lib.ml2048_encoder_front(None, 0, None, None, None, None, None, None, None, 0.01, None, None, None) == -1
     assert lib.ml2048_encoder_front(None, 8, 4100, 4096, 4096, 4096, 4096, 4096, 4096, 0.01, 4096, 4096, 4096) == -2
     assert lib.ml2048_timer_arm(None) == -1 and lib.ml2048_timer_elapsed_ms(None, None) == -1

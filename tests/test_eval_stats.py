@@ -100,3 +100,19 @@ def test_evaluate_helper_runs_a_policy_to_completion(amd):
     table, steps = amd.evaluate(env, amd.RandomPolicy(seed=1, masked=True), 300, check_every=8)
     assert sum(e["count"] for e in table.values()) == 300 and steps % 8 == 0
     assert abs(sum(e["share"] for e in table.values()) - 1.0) < 1e-12
+
+
+@pytest.mark.gpu
+def test_evaluate_on_a_reused_env_counts_from_its_game_counter(amd):
+    """`_game_count` survives reset() (game_numba.py:582 vs :606): on an env that has already played, "the first
+    N games" are the N ids dealt after the reset.  Same table as a fresh env with the same seed."""
+    fresh = amd.VecGame(256, "normal")
+    fresh.reset(5)
+    want, steps_want = amd.evaluate(fresh, amd.RandomPolicy(seed=1, masked=True), 300, check_every=8)
+    used = amd.VecGame(256, "normal")
+    used.reset(9)
+    used.rollout(200, masked=True)            # plays and re-deals: the game counter is far above zero
+    assert used._game_count > 256
+    used.reset(5)
+    got, steps_got = amd.evaluate(used, amd.RandomPolicy(seed=1, masked=True), 300, check_every=8, max_steps=20000)
+    assert got == want and steps_got == steps_want

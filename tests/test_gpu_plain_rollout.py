@@ -1,0 +1,148 @@
+"""GPU parity of the PLAIN fused-rollout instantiations - the kernels bench.py times - against the CPU oracle.
+
+`VecGame.rollout()` without `record_actions / digests / trajectory` launches `k_rollout<KIND, FAST, EXTRAS=false, INV>`
+(csrc/ml2048_hip.hip): lazy valid-mask loop, eight steps per loop iteration, inverse-permutation spawn on the
+expanded tables of the chained upload (`ml2048_rollout_chain`), and one of two separately compiled passes chosen by
+the board count (M <= 131 072: max-ilp scheduling + the lone-wave forms; larger M: default scheduling).  None of
+that code runs in the EXTRAS=true instantiation the digest-checking tests of test_gpu_parity.py use.
+
+The actions of such a rollout are a pure function of (act_seed, act_counter + t, board index) - and of the valid
+mask when masked - so the oracle replays them without any recording: game_numba.py:619-738 step for step, with
+`oracle.sample_actions` as the action source.  Every comparison is bit-exact (integer / byte / index work).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ACT_SEED = 7
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the GPU box"
+    import ml2048_amd
+
+    ml2048_amd._lib.load()  # must be the in-tree HIP library; raises otherwise
+    return ml2048_amd
+
+
+def _assert_same(env, ref, what):
+    a, b = env._data, ref._data
+    for f in ("id", "step", "score", "reward", "board", "merged", "valid_actions", "terminated", "invalid"):
+        assert np.array_equal(a[f], b[f]), f"{what}: field {f} differs"
+    assert a.tobytes() == b.tobytes(), what
+    assert np.array_equal(env._prev_state, ref._prev_state), f"{what}: prev_state"
+    assert np.array_equal(env._prev_valid_actions, ref._prev_valid_actions), f"{what}: prev_valid_actions"
+
+
+def _run(amd, oracle, M, lengths, reward, schedule, counter0, *, masked=False, seed=20241008, spawn="table",
+         ids="inline"):
+    """Back-to-back plain rollouts of the given lengths (the second and later launches of a host-async env consume
+    a schedule uploaded by the previous launch), each replayed by the oracle."""
+    kw = {}
+    if spawn == "rocrand":
+        env = amd.VecGame(M, reward, spawn="rocrand", spawn_seed=0xC0FFEE)
+        ref = oracle.OracleVecGame(M, reward, fast_seed=0xC0FFEE)
+    else:
+        env = amd.VecGame(M, reward, schedule=schedule)
+        ref = oracle.OracleVecGame(M, reward)
+    env.reset(seed)
+    ref.reset(seed)
+    counter = counter0
+    outs = []
+    for N in lengths:  # all launches first: nothing between two rollout kernels but what the product itself puts there
+        outs.append(env.rollout(N, masked=masked, act_seed=ACT_SEED, act_counter=counter,
+                                finish_ids="deferred" if ids == "deferred" else True, **kw))
+        counter += N
+    counter = counter0
+    expect_resets = []
+    for N in lengths:
+        resets = np.zeros(N, np.int32)
+        for t in range(N):
+            (ridx,) = ref.prepare()
+            resets[t] = ridx.size
+            a, _ = oracle.sample_actions(ref._data["valid_actions"], ACT_SEED, counter + t, masked=masked)
+            ref.step(a)
+        counter += N
+        expect_resets.append(resets)
+    env.join_ids()
+    for k, (out, exp) in enumerate(zip(outs, expect_resets)):
+        assert np.array_equal(out["step_resets"].cpu().numpy(), exp), f"step_resets of rollout {k}"
+    _assert_same(env, ref, f"M={M} lengths={lengths} {reward} {schedule}")
+    assert env._game_count == ref._game_count
+    assert env._rand_step == ref._rand_step  # closes the schedule stream: generator == what was executed
+    if spawn == "table":
+        assert np.array_equal(env._randperm, ref._randperm) and np.array_equal(env._randfloat, ref._randfloat)
+    # and the per-step API continues from exactly that state
+    (i1,) = env.prepare()
+    (i2,) = ref.prepare()
+    assert np.array_equal(i1, i2)
+    a = np.random.default_rng(M).integers(0, 4, size=M).astype(np.uint8)
+    env.step(a)
+    ref.step(a)
+    _assert_same(env, ref, "per-step call after the rollouts")
+    return env, ref
+
+
+# ---- the default bench path: schedule="host-async" -> ml2048_rollout_chain (expanded tables, INV spawn) -----------
+def test_plain_c2_twice_back_to_back(amd, oracle):
+    """BASELINE config 2 exactly as bench.py runs it (M=65 536, N=128, unmasked, host-async, deferred id scan):
+    the small-M pass, second launch on a chained upload."""
+    env, ref = _run(amd, oracle, 65536, [128, 128], "normal", "host-async", 0, ids="deferred")
+    assert ref._game_count > 65536  # games ended and were re-dealt inside the window
+
+
+@pytest.mark.parametrize("M,lengths,reward,counter0", [
+    (65536, [127, 65, 200], "improved", 13),   # remainder loop of the 8-step unroll; 64-step flag chunk edges
+    (131072, [128, 64], "rank", 0),            # largest M of the small-M pass
+    (131073, [128, 65], "maxcell", 77),        # smallest M of the large-M pass, ragged tail wave
+    (262144, [128, 128], "normal", 3),         # C4's per-GPU shard / C3's size
+    (1000, [200, 65, 1], "improved", 31),      # ragged small M
+    (63, [130], "rank", 5),
+])
+def test_plain_chain_matrix(amd, oracle, M, lengths, reward, counter0):
+    _run(amd, oracle, M, lengths, reward, "host-async", counter0, ids="deferred" if M % 2 == 0 else "inline")
+
+
+def test_plain_2m_boards_large_pass(amd, oracle):
+    """BASELINE config 4's total size as one plain rollout (large-M pass, 32 768 wavefronts)."""
+    _run(amd, oracle, 2097152, [128], "normal", "host-async", 1)
+
+
+# ---- the same kernels on the plain 16-byte table layout (schedule="host": ml2048_rollout, probing spawn) -----------
+@pytest.mark.parametrize("M,lengths,reward,counter0", [
+    (65536, [128, 65], "maxcell", 9),
+    (262144, [200, 127], "improved", 21),
+])
+def test_plain_sync_host_schedule(amd, oracle, M, lengths, reward, counter0):
+    _run(amd, oracle, M, lengths, reward, "host", counter0)
+
+
+# ---- schedule drawn on the GPU, expanded tables straight from csrc/devrng2.hip -------------------------------------
+@pytest.mark.parametrize("M,lengths,reward,counter0", [
+    (65536, [128, 65, 128], "normal", 9),
+    (262144, [128], "rank", 18),
+])
+def test_plain_device_schedule(amd, oracle, M, lengths, reward, counter0):
+    _run(amd, oracle, M, lengths, reward, "device", counter0)
+
+
+# ---- masked-uniform sampling without optional outputs: the eager-mask loop of the plain instantiations -------------
+@pytest.mark.parametrize("M,lengths,reward", [
+    (65536, [128, 127], "normal"),
+    (262144, [65], "maxcell"),
+])
+def test_plain_masked(amd, oracle, M, lengths, reward):
+    _run(amd, oracle, M, lengths, reward, "host-async", 4, masked=True)
+
+
+# ---- rocRAND spawn mode, plain instantiations (ml2048_rollout_fast without optional outputs) -----------------------
+@pytest.mark.parametrize("M,lengths,masked", [
+    (65536, [128, 64], False),
+    (262144, [65], True),
+])
+def test_plain_rocrand_spawn(amd, oracle, M, lengths, masked):
+    _run(amd, oracle, M, lengths, "improved", None, 11, masked=masked, spawn="rocrand")
