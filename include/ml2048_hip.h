@@ -426,9 +426,12 @@ typedef struct ml2048_step_out {
 
 /*
  *   actions / action_dtype / reward_kind / two_prob / idx_base        as ml2048_step
- *   randperm_step, randfloat_step, row_base_step                      step(t)'s tables and rand_step + rand_offset (:670,:681)
- *   randperm_prepare, randfloat_prepare, row_base_prepare             prepare(t+1)'s (:622-626, :651): other buffers than
+ *   randperm_step, two_mask_step, row_base_step                       step(t)'s permutation table, 2/4 mask and
+ *                                                                     rand_step + rand_offset (:670,:681)
+ *   randperm_prepare, two_mask_prepare, row_base_prepare              prepare(t+1)'s (:622-626, :651): another buffer than
  *                                                                     the step's when that prepare regenerated the tables
+ *   two_mask_*         bit c <=> float64(randfloat[c]) < two_prob for the 16 cells - all the reference ever reads of
+ *                      randfloat (it indexes by the CELL, :207; H1, H2); ml2048_hostrng_schedule's two_masks[] entries
  *   randperm_step == NULL selects the rocRAND spawn mode: spawn_seed with spawn_counter_step / spawn_counter_prepare
  *                                                                     as ml2048_step_fast / ml2048_prepare_fast take them
  *   game_count, n_reset, reset_indices (may be NULL)                  as ml2048_prepare
@@ -450,11 +453,10 @@ typedef struct ml2048_step_prepare_args {
     int32_t action_dtype, reward_kind;
     double two_prob;
     const uint8_t *randperm_step;
-    const float *randfloat_step;
     int64_t row_base_step;
     const uint8_t *randperm_prepare;
-    const float *randfloat_prepare;
     int64_t row_base_prepare;
+    uint32_t two_mask_step, two_mask_prepare;
     uint64_t spawn_seed, spawn_counter_step, spawn_counter_prepare;
     int32_t *game_count;
     int32_t *n_reset;

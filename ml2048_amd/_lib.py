@@ -44,8 +44,9 @@ class StepPrepareArgs(C.Structure):
 
     _fields_ = [("M", C.c_int64), ("idx_base", C.c_int64), ("st", State), ("actions", C.c_void_p),
                 ("action_dtype", C.c_int32), ("reward_kind", C.c_int32), ("two_prob", C.c_double),
-                ("randperm_step", C.c_void_p), ("randfloat_step", C.c_void_p), ("row_base_step", C.c_int64),
-                ("randperm_prepare", C.c_void_p), ("randfloat_prepare", C.c_void_p), ("row_base_prepare", C.c_int64),
+                ("randperm_step", C.c_void_p), ("row_base_step", C.c_int64),
+                ("randperm_prepare", C.c_void_p), ("row_base_prepare", C.c_int64),
+                ("two_mask_step", C.c_uint32), ("two_mask_prepare", C.c_uint32),
                 ("spawn_seed", C.c_uint64), ("spawn_counter_step", C.c_uint64), ("spawn_counter_prepare", C.c_uint64),
                 ("game_count", C.c_void_p), ("n_reset", C.c_void_p), ("reset_indices", C.c_void_p),
                 ("scratch", C.c_void_p), ("out", StepOut), ("onehot", C.c_void_p), ("board_i64", C.c_void_p),

@@ -115,11 +115,7 @@ __global__ __launch_bounds__(kBlk) void k_step_prepare(const ml2048_step_prepare
     // every other workgroup's count, i.e. after all of them have read these
     const uint32_t epoch = *epoch_p + 1u;
     const int32_t gc0 = *a.game_count;
-    uint32_t two_s = 0, two_p = 0;
-    if (!FAST) { // wave-wide ballots: every lane takes part (H1: randfloat is indexed by the CELL)
-        two_s = two_mask_from_table(a.randfloat_step, a.two_prob);
-        two_p = two_mask_from_table(a.randfloat_prepare, a.two_prob);
-    }
+    const uint32_t two_s = a.two_mask_step, two_p = a.two_mask_prepare; // H1: randfloat is indexed by the CELL
     if (a.hist_counts) { // wave-uniform
         if (threadIdx.x < 20) hist[threadIdx.x] = 0;
         __syncthreads();
@@ -218,7 +214,7 @@ __global__ __launch_bounds__(kBlk) void k_step_prepare(const ml2048_step_prepare
         if (w < wave) below += wave_cnt[w];
     }
     if (threadIdx.x == 0)
-        __hip_atomic_store(status + b, ((unsigned long long)epoch << 32) | (uint32_t)tot, __ATOMIC_RELEASE,
+        __hip_atomic_store(status + b, ((unsigned long long)epoch << 32) | (uint32_t)tot, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     if (a.hist_counts && threadIdx.x < 20 && hist[threadIdx.x]) atomicAdd(&a.hist_counts[threadIdx.x], hist[threadIdx.x]);
 
@@ -275,14 +271,28 @@ __global__ __launch_bounds__(kBlk) void k_step_prepare(const ml2048_step_prepare
     }
 
     // ---- phase 2b: exclusive prefix of the workgroup counts (every lower workgroup has published, or will) --------
+    // Relaxed device-scope accesses on both sides: the word itself (tag + count) is all that is consumed, so nothing
+    // has to be released or acquired.  (First build: release store + acquire loads = an L2 write-back per workgroup
+    // and an L1 invalidate per probe, and the <= 4 probes of a thread one after the other: 36 us per launch at
+    // 262 144 boards against 8 + 14 us for the separate step and prepare kernels.)  All probes of a thread are issued
+    // before the first is looked at; a word that is not there yet is polled.
+    constexpr int kProbes = kMaxBlocks / kBlk;
+    unsigned long long v[kProbes];
+#pragma unroll
+    for (int q = 0; q < kProbes; ++q) {
+        const int j = (int)threadIdx.x + q * kBlk;
+        v[q] = j < b ? __hip_atomic_load(status + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                     : ((unsigned long long)epoch << 32);
+    }
     int part = 0;
-    for (int j = (int)threadIdx.x; j < b; j += kBlk) {
-        unsigned long long v = __hip_atomic_load(status + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-        while ((uint32_t)(v >> 32) != epoch) {
+#pragma unroll
+    for (int q = 0; q < kProbes; ++q) {
+        const int j = (int)threadIdx.x + q * kBlk;
+        while ((uint32_t)(v[q] >> 32) != epoch) { // only ever true for j < b
             __builtin_amdgcn_s_sleep(1);
-            v = __hip_atomic_load(status + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            v[q] = __hip_atomic_load(status + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        part += (int)(uint32_t)v;
+        part += (int)(uint32_t)v[q];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
@@ -334,8 +344,9 @@ int ml2048_step_prepare(void *stream, const ml2048_step_prepare_args *a) {
     if (a->action_dtype < 0 || a->action_dtype > 2) return ml2048_internal_fail(ML2048_E_INVALID, "action_dtype=%d", a->action_dtype);
     if (a->reward_kind < 0 || a->reward_kind > 3) return ml2048_internal_fail(ML2048_E_INVALID, "reward_kind=%d", a->reward_kind);
     if (!fast) {
-        if (!a->randfloat_step || !a->randperm_prepare || !a->randfloat_prepare)
-            return ml2048_internal_fail(ML2048_E_INVALID, "randfloat_step/randperm_prepare/randfloat_prepare is NULL");
+        if (!a->randperm_prepare) return ml2048_internal_fail(ML2048_E_INVALID, "randperm_prepare is NULL");
+        if ((a->two_mask_step | a->two_mask_prepare) >> 16)
+            return ml2048_internal_fail(ML2048_E_INVALID, "two_mask_* have 16 bits (one per cell)");
         if (((uintptr_t)a->randperm_step | (uintptr_t)a->randperm_prepare) % 16)
             return ml2048_internal_fail(ML2048_E_ALIGN, "randperm_* must be 16-byte aligned");
         if (a->row_base_step < 0 || a->row_base_prepare < 0)

@@ -37,9 +37,19 @@ class EpisodeStats:
 
     def on_stepped(self, game=None, result=None, actions=None, action_log_probs=None) -> None:
         env = self.env
+        st = env._st()
+        if result is not None and "id" in result:
+            # fused runner (VecRunner(fused=True)): the live state already shows the re-dealt games; the step's
+            # outcome - ids included - is in the result's own arrays
+            key = tuple(result[k].data_ptr() for k in ("id", "terminated", "state", "score"))
+            if key != getattr(self, "_res_key", None):
+                s2 = _lib.State.from_buffer_copy(env._state)
+                s2.id, s2.terminated, s2.board, s2.score = key
+                self._res_key, self._res_state = key, s2
+            st = C.byref(self._res_state)
         with env._dev_ctx():
             _lib.check(env._L.ml2048_episode_stats(
-                env._stream(), env._size, env._st(), self._age.data_ptr(), self._seen.data_ptr(), self.id_base, self.rounds,
+                env._stream(), env._size, st, self._age.data_ptr(), self._seen.data_ptr(), self.id_base, self.rounds,
                 self._acc[0].data_ptr(), self._acc[1].data_ptr(), self._acc[2].data_ptr()), "episode_stats")
 
     def completed(self) -> int:
@@ -63,14 +73,15 @@ class EpisodeStats:
         return out
 
 
-def evaluate(env: VecGame, policy, rounds: int, *, check_every: int = 16, max_steps: int = 1_000_000):
+def evaluate(env: VecGame, policy, rounds: int, *, check_every: int = 16, max_steps: int = 1_000_000,
+             fused: bool = False):
     """Play `policy` until the first `rounds` games have all terminated (eval_perf.py:77-99); returns
     (table, env steps played).  The completion test costs a device sync, so it runs every
     `check_every` steps - the table itself only ever contains games with id < rounds."""
     from .runner import VecRunner
 
     stats = EpisodeStats(env, rounds)
-    runner = VecRunner(env, env._size)
+    runner = VecRunner(env, env._size, fused=fused, out_names=("id", "terminated", "state", "score") if fused else None)
     runner.add_callback(VecRunner.EVENT_STEPPED, stats.on_stepped)
     steps = 0
     while steps < max_steps:

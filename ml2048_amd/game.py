@@ -139,6 +139,7 @@ class _NullCtx:
 
 
 _NULL_CTX = _NullCtx()
+_NO_NEXT = (None, None)
 
 
 class VecGame:
@@ -234,6 +235,8 @@ class VecGame:
         self._scratch = torch.zeros((int(self._L.ml2048_scratch_ints(M)),), dtype=i32, device=dev)  # zeroed once
         self._hist = torch.zeros((20,), dtype=i32, device=dev)
         self._fast_counter = 0
+        self._serial = 0            # bumped by every call that changes game state (callers cache things keyed on it)
+        self._prepared = False      # True between a prepare (or step_prepare) and the next step
         self._devrng = torch.zeros((6,), dtype=torch.int64, device=dev)  # struct ml2048_devrng
         self._devrng_ws = None
         self._sched_stream = None
@@ -402,8 +405,13 @@ class VecGame:
             break
         return slot, (int(ne.value), int(o_s.value), int(o_m.value), int(nb.value)), (after, rs.value, slot[2], slot[3])
 
-    def _pull_rng(self) -> None:
+    def _pull_rng(self, sync_lookahead: bool = True) -> None:
         """Make the host generator current again (before any host-side draw or inspection)."""
+        if sync_lookahead and self._rng._la is not None:
+            # draws taken ahead by step_prepare_torch: back to what was consumed; the per-step API's device tables were
+            # not kept up to date meanwhile (the fused kernel reads the lookahead block's own device copy)
+            self._rng.sync()
+            self._tables_dirty = True
         self._close_sched_stream()
         if not self._rng_on_device:
             return
@@ -473,6 +481,8 @@ class VecGame:
     def load_records(self, records: np.ndarray) -> None:
         """Overwrite the device state from reference-layout records (tests / restoring a run)."""
         rec = np.ascontiguousarray(records).view(np.uint8).reshape(self._size, 64)
+        self._serial += 1
+        self._prepared = False
         dev = torch.from_numpy(rec).to(self.device)
         with self._dev_ctx():
             _lib.check(self._L.ml2048_unpack_records(self._stream(), self._size, self._st(), dev.data_ptr()), "unpack_records")
@@ -520,6 +530,8 @@ class VecGame:
         self._rng_on_device = False
         self._rng = HostRng(seed)
         self._fast_counter = 0
+        self._serial += 1
+        self._prepared = False
         self._upload_tables()
         with self._dev_ctx():
             _lib.check(self._L.ml2048_reset(self._stream(), self._size, self._st()), "reset")
@@ -553,6 +565,8 @@ class VecGame:
                     2 * self._fast_counter, self._game_count_dev.data_ptr(), self._n_reset_dev.data_ptr(),
                     self._reset_indices.data_ptr(), self._scratch.data_ptr())
         _lib.check(rc, "prepare")
+        self._serial += 1
+        self._prepared = True
         return self._reset_indices, self._n_reset_dev
 
     def prepare(self) -> tuple[np.ndarray]:
@@ -594,6 +608,8 @@ class VecGame:
                                         2 * self._fast_counter + 1)
                 self._fast_counter += 1
         _lib.check(rc, "step")
+        self._serial += 1
+        self._prepared = False
         return {
             "state": self.board, "valid_actions": self.valid_actions, "merged": self.merged,
             "step": self.step_count, "reward": self.reward, "score": self.score,
@@ -605,6 +621,161 @@ class VecGame:
         """game_numba.py:660-698, returning host snapshots of the ten result arrays."""
         res = self.step_torch(actions)
         return {k: v.cpu().numpy() for k, v in res.items()}  # type: ignore[return-value]
+
+    # ------------------------------------------------------------------------------------------
+    STEP_OUT_SPEC = {  # ml2048_step_out: name -> (trailing shape, accepted dtypes)
+        "state": ((16,), (torch.uint8, torch.int8)), "valid_actions": ((4,), (torch.uint8, torch.bool)),
+        "merged": ((16,), (torch.uint8,)), "step": ((), (torch.int32,)), "reward": ((), (torch.float32,)),
+        "score": ((), (torch.float32,)), "terminated": ((), (torch.uint8, torch.bool)),
+        "invalid": ((), (torch.uint8, torch.bool)), "id": ((), (torch.int32,)),
+        "prev_state": ((16,), (torch.uint8, torch.int8)), "prev_valid_actions": ((4,), (torch.uint8, torch.bool)),
+    }
+
+    def new_step_out(self, names=None) -> dict:
+        """Buffers for `step_prepare_torch(out=...)`: the reference's VecStepResult arrays (+ "id")."""
+        names = list(self.STEP_OUT_SPEC) if names is None else list(names)
+        return {n: torch.empty((self._size, *self.STEP_OUT_SPEC[n][0]), dtype=self.STEP_OUT_SPEC[n][1][0],
+                               device=self.device) for n in names}
+
+    def _sp_args(self):
+        A = getattr(self, "_sp", None)
+        if A is None:
+            L = self._L
+            A = _lib.StepPrepareArgs()
+            A.M, A.idx_base, A.st = self._size, self._idx_base, self._state
+            A.reward_kind, A.two_prob = self._reward_kind, self._two_prob
+            A.spawn_seed = self._spawn_seed
+            A.game_count, A.n_reset = self._game_count_dev.data_ptr(), self._n_reset_dev.data_ptr()
+            A.reset_indices = self._reset_indices.data_ptr()
+            nbytes = int(L.ml2048_step_prepare_scratch_bytes())
+            self._sp_scratch = torch.zeros((nbytes // 8,), dtype=torch.int64, device=self.device)  # zeroed once
+            A.scratch = self._sp_scratch.data_ptr()
+            self._sp = A
+            self._sp_ref = C.byref(A)
+            self._sp_out = None      # the `out` dict whose pointers are in A.out
+            self._sp_obs = (None, None, None)  # (onehot, board_i64, hist) whose pointers are in A
+            self._sp_next = [None, None]  # ping-pong (actions, logp) buffers of the fused sampler
+            self._sp_k = 0
+            self._sp_sampling = False
+            self._sp_block = None    # the lookahead block (HostRng.next_step_prepare) whose tables are on the device
+            self._sp_block_dev = None
+            self._sp_block_ptr = 0
+            self._sp_stage = [None, None, None]  # pinned staging ring: [buffer, event of the copy kernel that read it]
+            self._sp_stage_i = 0
+        return A
+
+    def _sp_upload_block(self, blk) -> None:
+        """The epoch tables of a lookahead block (HostRng.next_step_prepare) -> one device array, by the copy kernel
+        that reads pinned host memory (ml2048_upload): no hipMemcpyAsync (which can stall the host for milliseconds
+        behind queued kernels) and no host-device synchronisation inside a step_prepare loop."""
+        tabs = blk[2]  # uint8[E, 1024, 16]
+        nbytes = int(tabs.size)
+        ring = self._sp_stage
+        i = self._sp_stage_i
+        self._sp_stage_i = (i + 1) % len(ring)
+        slot = ring[i]
+        if slot is not None and slot[1] is not None:
+            slot[1].synchronize()  # the copy kernel that read this staging buffer (three blocks ago) has finished
+        if slot is None or slot[0].numel() < nbytes:
+            slot = [torch.empty((max(nbytes, 48 * RAND_SIZE * 16),), dtype=torch.uint8, pin_memory=True), None]
+            ring[i] = slot
+        slot[0].numpy()[:nbytes] = tabs.reshape(-1)
+        # the previous block's device array goes back to the caching allocator, whose reuse is ordered on this stream
+        self._sp_block_dev = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
+        _lib.check(self._L.ml2048_upload(self._stream(), self._sp_block_dev.data_ptr(), slot[0].data_ptr(), nbytes, 0),
+                   "upload")
+        if slot[1] is None:
+            slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(self.device))
+        self._sp_block_ptr = self._sp_block_dev.data_ptr()
+        self._sp_block = blk
+
+    def step_prepare_torch(self, actions, *, out: Optional[dict] = None, onehot: Optional[torch.Tensor] = None,
+                           board_i64: Optional[torch.Tensor] = None, sample=None,
+                           hist: Optional[torch.Tensor] = None):
+        """step(actions) and the following prepare() as ONE launch (`ml2048_step_prepare`): same draws, same
+        state, ids and index list as `step_torch(actions); prepare_torch()`.  Afterwards the live tensors
+        (`board`, `valid_actions`, ...) show the re-dealt games, i.e. what the next policy call observes.
+
+        out:       dict of device tensors keyed like VecStepResult (+ "id"), see `new_step_out()`: what step()
+                   returned, as of before the re-deal (the reference's result views).  May hold slices of replay
+                   buffers (int8 / bool views of the same bytes are accepted).
+        onehot:    (M,16,4,4) float32 tensor to receive the observation of the post-prepare boards;
+        board_i64: (M,16) int64 likewise.
+        sample:    a RandomPolicy: its draw for the NEXT step on the post-prepare masks comes out of the same
+                   launch (the policy's call counter advances as if sample_actions_u8 had been called).
+        hist:      int32[20] accumulator of the max tile of the games this step finished (RunnerStats).
+        Returns {"n_reset": (1,) int32, "reset_indices": (M,) int64 buffer, "actions": uint8 (M,) | None,
+        "log_probs": float32 (M,) | None} - all device tensors, no host sync.
+        """
+        M, dev = self._size, self.device
+        if torch.is_tensor(actions) and actions.dtype == torch.uint8 and actions.device == dev and \
+                actions.ndim == 1 and actions.shape[0] == M and actions.is_contiguous():
+            a = actions  # the common case (the fused sampler's own output): no conversions
+        else:
+            a = self._as_device_actions(actions)
+        if getattr(self, "_prefetch", None) is not None:
+            self._drop_prefetch()
+        if self._sstream is not None or self._rng_on_device:
+            self._pull_rng(sync_lookahead=False)
+        A = self._sp_args()
+        A.actions, A.action_dtype = a.data_ptr(), _ACT_CODE[a.dtype]
+        with self._dev_ctx():
+            if self._spawn == "table":
+                # step(t)'s draw (:670), then the following prepare()'s (:622-626), from the block of draws taken
+                # ahead; the block's epoch tables live on the device as one array, so a regeneration is a pointer change
+                A.row_base_step, A.row_base_prepare, e_s, e_p, blk = self._rng.next_step_prepare(self._two_prob)
+                if blk is not self._sp_block:
+                    self._sp_upload_block(blk)
+                masks = blk[7]
+                A.randperm_step = self._sp_block_ptr + e_s * (RAND_SIZE * 16)
+                A.two_mask_step = masks[e_s]
+                A.randperm_prepare = self._sp_block_ptr + e_p * (RAND_SIZE * 16)
+                A.two_mask_prepare = masks[e_p]
+            else:
+                A.randperm_step = None
+                A.spawn_counter_step = 2 * self._fast_counter + 1
+                self._fast_counter += 1
+                A.spawn_counter_prepare = 2 * self._fast_counter
+            if out is not self._sp_out:
+                for name, (shape, dts) in self.STEP_OUT_SPEC.items():
+                    buf = None if out is None else out.get(name)
+                    if buf is not None:
+                        assert buf.is_contiguous() and buf.dtype in dts and buf.device == dev and \
+                            tuple(buf.shape) == (M, *shape), (name, buf.dtype, tuple(buf.shape))
+                    setattr(A.out, name, None if buf is None else buf.data_ptr())
+                self._sp_out = out
+            if onehot is not self._sp_obs[0] or board_i64 is not self._sp_obs[1] or hist is not self._sp_obs[2]:
+                if onehot is not None:
+                    assert onehot.shape == (M, 16, 4, 4) and onehot.dtype == torch.float32 and onehot.is_contiguous()
+                if board_i64 is not None:
+                    assert board_i64.shape == (M, 16) and board_i64.dtype == torch.int64 and board_i64.is_contiguous()
+                A.onehot = None if onehot is None else onehot.data_ptr()
+                A.board_i64 = None if board_i64 is None else board_i64.data_ptr()
+                A.hist_counts = None if hist is None else hist.data_ptr()
+                self._sp_obs = (onehot, board_i64, hist)
+            nxt = _NO_NEXT
+            if sample is not None:
+                k = self._sp_k
+                self._sp_k = k ^ 1
+                nxt = self._sp_next[k]  # two sets: this launch writes set k while it reads set k^1 as `actions`
+                if nxt is None:
+                    nxt = (torch.empty((M,), dtype=torch.uint8, device=dev), torch.empty((M,), dtype=torch.float32, device=dev))
+                    self._sp_next[k] = nxt
+                    assert sample.idx_base == self._idx_base
+                A.next_actions, A.next_logp = nxt[0].data_ptr(), nxt[1].data_ptr()
+                A.act_seed, A.act_counter, A.act_masked = sample.seed, sample.counter, int(sample.masked)
+                sample.counter += 1
+                self._sp_sampling = True
+            elif self._sp_sampling:
+                A.next_actions = A.next_logp = None
+                self._sp_sampling = False
+            rc = self._L.ml2048_step_prepare(self._stream(), self._sp_ref)
+        if rc:
+            _lib.check(rc, "step_prepare")
+        self._serial += 1
+        self._prepared = True
+        return {"n_reset": self._n_reset_dev, "reset_indices": self._reset_indices, "actions": nxt[0], "log_probs": nxt[1]}
 
     # ------------------------------------------------------------------------------------------
     def onehot(self, out: Optional[torch.Tensor] = None, *, with_long: bool = False, check: bool = False):
@@ -741,6 +912,11 @@ class VecGame:
         if N <= 0:
             raise ValueError(f"n_steps={n_steps}")
         L = self._L
+        self._serial += 1
+        self._prepared = False
+        if self._rng._la is not None:  # draws taken ahead by step_prepare_torch: back to what was consumed
+            self._rng.sync()
+            self._tables_dirty = True
         fast = self._spawn != "table"
         on_device = (not fast) and self._schedule_mode == "device"
         dev_expanded = False

@@ -16,6 +16,18 @@ import numpy as np
 
 RAND_SIZE = 1024  # VecGame._RAND_SIZE, game_numba.py:533
 
+_LA_POOL = None
+
+
+def _la_pool():
+    """One worker thread for all lookahead blocks of the process (HostRng.next_step_prepare)."""
+    global _LA_POOL
+    if _LA_POOL is None:
+        import concurrent.futures as cf
+
+        _LA_POOL = cf.ThreadPoolExecutor(max_workers=1, thread_name_prefix="ml2048-hostrng-la")
+    return _LA_POOL
+
 
 class HostRng:
     def __init__(self, seed: Optional[int] = None):
@@ -25,6 +37,7 @@ class HostRng:
         self.randfloat = np.empty((RAND_SIZE,), dtype=np.float32)
         self.randperm[:, :] = np.arange(16).reshape((1, 16))  # :610
         self.epoch = 0  # number of table regenerations so far (bookkeeping only)
+        self._la = None  # draws taken ahead for step_prepare loops (see next_step_prepare)
         self._reset_rand()  # :611
 
     def clone(self) -> "HostRng":
@@ -37,6 +50,7 @@ class HostRng:
         c.randperm = self.randperm.copy()
         c.randfloat = self.randfloat.copy()
         c.epoch = self.epoch
+        c._la = None
         return c
 
     # game_numba.py:589-591 - permuted() works in place, so successive tables compose
@@ -90,6 +104,74 @@ class HostRng:
         row_base = self.rand_step + rand_offset
         self.rand_step += 1
         return row_base
+
+    # ---- draws ahead for a loop of {step(t); prepare(t+1)} calls (VecGame.step_prepare_torch) ----------------------
+    # numpy's Generator costs ~2.5 us per integers() call; a loop that issues one 8 us kernel per env step cannot afford
+    # three of them.  The draw order is state-independent, so a block of LOOKAHEAD (prepare, step)
+    # pairs is drawn by ONE native call (draw_schedule) and handed out pair by pair.  The object then runs AHEAD of
+    # what the env has consumed; `sync()` puts it back to exactly the consumed position (by replaying the consumed part
+    # of the block from a clone taken at its start) and must precede anything else that touches rand / rand_step / the
+    # tables.  Consumption order per call: the pending step draw, then the next prepare's draws.
+    LOOKAHEAD = 128
+
+    @staticmethod
+    def _la_block(start: "HostRng", n: int, two_prob: float):
+        """One block of n (prepare, step) pairs drawn from a copy of `start` (which stays at the block's start for
+        sync() to replay from).  Runs on the caller's thread or on the lookahead worker (the native call drops the GIL)."""
+        after = start.clone()
+        sched, epochs, masks = after.draw_schedule(n, two_prob)
+        return after, sched.tolist(), epochs, masks.tolist()
+
+    def next_step_prepare(self, two_prob: float):
+        """Draws of step(t) followed by prepare(t+1): -> (row_base_step, row_base_prepare, e_step, e_prepare, block).
+        `block` is the lookahead block the draws come from (a list; block[2] = its epoch tables uint8[E,1024,16],
+        block[7] = their 2/4 masks - all the reference reads of randfloat, H1); e_step / e_prepare index the tables in
+        force for the step and after the prepare (they differ when that prepare regenerated the tables).  A new block
+        object means new tables: its epoch 0 is the table the previous block ended with."""
+        la = self._la
+        if la is None or la[4] == la[5]:
+            if la is None:
+                step_row = self.draw_step()
+                start = self.clone()
+                block = self._la_block(start, self.LOOKAHEAD, two_prob)
+            else:  # block exhausted: its last draw - a step - is still pending; the next block was drawn meanwhile
+                step_row, start = la[3], la[10]
+                block = la[9].result()
+            after, sched, epochs, masks = block
+            # this object moves to the END of the block (sync() brings it back to what was consumed) ...
+            self.rand, self.rand_step, self.epoch = after.rand, after.rand_step, after.epoch
+            self.randperm[...] = after.randperm
+            self.randfloat[...] = after.randfloat
+            # ... and the block after it is drawn on the worker thread while this one is handed out
+            nstart = after.clone()
+            fut = _la_pool().submit(self._la_block, nstart, self.LOOKAHEAD, two_prob)
+            #                0      1      2       3         4  5               6  7      8         9    10
+            la = self._la = [start, sched, epochs, step_row, 0, self.LOOKAHEAD, 0, masks, two_prob, fut, nstart]
+        row_s, e_s = la[3], la[6]
+        e_p, row_p, la[3] = la[1][la[4]]
+        la[4] += 1
+        la[6] = e_p
+        return row_s, row_p, e_s, e_p, la
+
+    def sync(self) -> None:
+        """Back to exactly what has been consumed (no-op without a lookahead)."""
+        la = self._la
+        if la is None:
+            return
+        self._la = None
+        j = la[4]  # consumed of the block: pairs 1..j-1 and the prepare of pair j (its step is pending, unused)
+        start = la[0]
+        if j >= 2:
+            start.draw_schedule(j - 1, la[8])
+        if j >= 1:
+            start.draw_prepare()
+        else:  # nothing of the block consumed, but the pending step was drawn before its start: cannot happen after
+            raise AssertionError("lookahead block with nothing consumed")  # a call (j >= 1), kept as a guard
+        self.rand = start.rand
+        self.rand_step = start.rand_step
+        self.randperm[...] = start.randperm
+        self.randfloat[...] = start.randfloat
+        self.epoch = start.epoch
 
     def two_mask(self, two_prob: float) -> int:
         """bit c <=> float64(randfloat[c]) < two_prob: the only part of randfloat the reference

@@ -10,6 +10,7 @@ from typing import Any, Callable, Sequence
 import numpy as np
 import torch
 
+from . import _lib
 from .game import VecGame, VecStepResult
 from .policy import Policy, RandomPolicy
 
@@ -44,19 +45,59 @@ class VecRunner:
     EVENT_PREPARED = "prepared"
     EVENT_STEPPED = "stepped"
 
-    def __init__(self, env: VecGame, capacity: int = 0, *, sample_device=None, long_state: bool = True):
+    def __init__(self, env: VecGame, capacity: int = 0, *, sample_device=None, long_state: bool = True,
+                 fused: bool = False, out_names=None):
+        """fused=True: one launch per env step (`VecGame.step_prepare_torch`: step(t) and prepare(t+1) in one kernel;
+        a RandomPolicy's next draw comes out of the same launch).  Same events in the same order with the same
+        contents; `result` then holds the step's outcome in buffers owned by the runner (the reference's views are
+        clobbered by the next prepare() just the same), plus "id" (the games' ids as of the step).
+        out_names: which of VecGame.STEP_OUT_SPEC's arrays `result` needs (default: all of them, 74 B/board)."""
         self.env = env
         self.sample_device = sample_device if sample_device is not None else env.device
         self._emitter = EventEmitter()
         self._vec_size = env._size  # runner.py:57
         self._capacity = capacity
         self._long_state = long_state
+        self._fused = fused
+        self._out = env.new_step_out(out_names) if fused else None
+        self._next = None  # fused + RandomPolicy: (actions, log_probs, env serial, policy, policy counter)
 
     def add_callback(self, event: str, fn: Callable[..., Any]) -> None:
         assert event in {self.EVENT_STEPPED, self.EVENT_PREPARED}
         self._emitter.add_listener(event, fn)
 
+    def _step_once_fused(self, policy: Policy) -> VecStepResult:
+        env = self.env
+        want_prepared = self._emitter.has_listeners(self.EVENT_PREPARED)
+        if not env._prepared:  # first step (or another API stepped the env): deal as prepare() does
+            if want_prepared:
+                (new_indices,) = env.prepare()
+                self._emitter.emit(self.EVENT_PREPARED, (env, new_indices))
+            else:
+                env.prepare_torch()
+        board, valid = env.observations_torch()
+        is_random = isinstance(policy, RandomPolicy) and policy.idx_base == env._idx_base
+        with torch.no_grad():
+            nx = self._next
+            if is_random and nx is not None and nx[2] == env._serial and nx[3] is policy and nx[4] == policy.counter:
+                actions, log_probs = nx[0], nx[1]  # drawn by the previous launch on these very masks
+            elif isinstance(policy, RandomPolicy):
+                actions, log_probs = policy.sample_actions_u8(valid)
+            else:
+                state = board.to(torch.long) if self._long_state else board
+                actions, log_probs = policy.sample_actions(state, valid.to(torch.bool))
+        res = env.step_prepare_torch(actions, out=self._out, sample=policy if is_random else None)
+        self._next = (res["actions"], res["log_probs"], env._serial, policy, policy.counter) if is_random else None
+        result = dict(self._out)
+        self._emitter.emit(self.EVENT_STEPPED, (env, result, actions, log_probs))
+        if want_prepared:  # the prepare() of the NEXT step already ran: same event, same place in the sequence
+            k = int(res["n_reset"].item())
+            self._emitter.emit(self.EVENT_PREPARED, (env, res["reset_indices"][:k].cpu().numpy()))
+        return result  # type: ignore[return-value]
+
     def step_once(self, policy: Policy) -> VecStepResult:
+        if self._fused:
+            return self._step_once_fused(policy)
         env = self.env
         if self._emitter.has_listeners(self.EVENT_PREPARED):
             (new_indices,) = env.prepare()
@@ -110,8 +151,13 @@ class RunnerStats:
         if self._dev is None:
             self._dev = torch.zeros((20,), dtype=torch.int32, device=game.device)
             self._term = torch.zeros((1,), dtype=torch.int64, device=game.device)
-        game.histogram(terminated_only=True, out=self._dev)  # _update_count, runner.py:120-136
-        self._term += result["terminated"].sum()
+        # _update_count(counts, result["state"], result["terminated"]), runner.py:120-136, on the result's own arrays
+        # (the live state in the per-step mode; the runner's outcome buffers in the fused mode)
+        state, term = result["state"], result["terminated"]
+        with game._dev_ctx():
+            _lib.check(game._L.ml2048_hist_maxcell(game._stream(), game._size, state.data_ptr(), term.data_ptr(),
+                                                   self._dev.data_ptr()), "hist")
+        self._term += term.sum()
 
     def sync(self) -> None:
         """Fold the device accumulators into `counts` / `terminated_count` (one small D2H)."""
