@@ -11,14 +11,22 @@ data-path collective; the only collective is the timing barrier / max).  `value`
 board-steps/s with all inputs resident in HBM.
 
 The JSON line also carries
-  roofline      the dominant kernel's algorithmic bytes / its HIP-event-timed duration vs 8 TB/s
+  roofline      for the dominant kernel, against the bound it actually touches:
+                  fused modes     VALU issue: wave-instructions/s (instructions per wave-step from a committed
+                                  rocprofv3 SQ-counter profile x waves x steps / the kernel's HIP-event duration)
+                                  vs CUs x 4 SIMDs x clock / 2 cycles; the 99 B/board-step HBM-equivalent is a
+                                  side figure, never `frac`
+                  per-step modes  HBM: algorithmic bytes of the one launch per env step / its duration vs 8 TB/s
   cpu_baseline  the CPU oracle (a bit-exact C/OpenMP restatement of the reference, "port") timed
                 on this host on a bounded sample of the same workload (rank 0, N=1 only)
-  stepwise      the same workload through the per-step API (prepare/sample/step launches)
+  extras        (rank 0, N=1, default mode) the same C2 workload one launch per env step, C3 (M=262144, masked
+                sampling + one-hot observation per env step), the fused rollout at C4's per-GPU shard size, and the
+                rocRAND spawn mode
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import subprocess
@@ -33,31 +41,36 @@ if ROOT not in sys.path:
 BYTES_PER_BOARD_STEP = 99  # SURVEY.md 8d / BASELINE.md 4: algorithmic bytes of one env step (no obs)
 BYTES_PER_BOARD_STEP_OBS = 1128  # with masked sampling + fp32 one-hot
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# VALU issue (same guide, "SIMD-32": a wave64 VALU instruction issues over 2 cycles; one wave ALONE on its SIMD
+# sustains one per 4): 256 CUs x 4 SIMDs x 2.4 GHz / 2
+N_SIMD, CLOCK_GHZ = 256 * 4, 2.4
+VALU_PEAK_GINST = N_SIMD * CLOCK_GHZ / 2.0
+LONE_WAVE_PEAK_GINST = N_SIMD * CLOCK_GHZ / 4.0
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)  # 0.12 s timed at C2: long enough to average out host jitter
+    ap.add_argument("--steps", type=int, default=1000)  # 0.1 s timed at C2: long enough to average out host jitter
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--boards", type=int, default=65536, help="M per GPU (C2: 65536)")
     ap.add_argument("--env-steps", type=int, default=128, help="N env steps per bench step (C2: 128)")
-    ap.add_argument("--mode", choices=["fused", "fused-traj", "stepwise", "obs"], default="fused",
-                    help="fused: one rollout launch per bench step (default); stepwise: per-step API; "
-                         "obs: per-step API + masked sampling + one-hot (C3 pipeline)")
-    ap.add_argument("--masked", type=int, default=0, help="masked-uniform actions (default: unmasked, C2)")
+    ap.add_argument("--mode", choices=["fused", "fused-traj", "stepwise", "obs", "stepwise3"], default="fused",
+                    help="fused: one rollout launch per bench step (default); stepwise: one ml2048_step_prepare "
+                         "launch per env step; obs: the same with masked sampling + the one-hot observation "
+                         "(C3 pipeline); stepwise3: the reference-shaped per-step API (prepare, sample, step launches)")
+    ap.add_argument("--masked", type=int, default=None, help="masked-uniform actions (default: unmasked, C2; obs: masked)")
     ap.add_argument("--seed", type=int, default=20241008)
     ap.add_argument("--step-mapping", choices=["lane", "wave"], default="lane",
-                    help="per-step kernel mapping: lane-per-board (default) or one wavefront per board")
+                    help="stepwise3: lane-per-board step kernel (default) or one wavefront per board")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary stepwise measurement")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--ids", choices=["deferred", "inline"], default="deferred",
                     help="fused mode: where the ordered game-id scan of a rollout runs - 'deferred' = on a side "
                          "stream beside the next rollout's kernel, 'inline' = on the launch stream")
     ap.add_argument("--event-every", type=int, default=8,
-                    help="bracket every k-th timed launch of the dominant kernel with HIP events (the pair of "
-                         "timestamp packets costs a few us of GPU idle per launch, so not every launch carries one)")
+                    help="attach a HIP event pair to every k-th timed launch of the dominant kernel")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the barrier / max-over-ranks (nccl = RCCL; gloo only for "
                          "rehearsing the N>1 launch contract on a box with fewer GPUs than ranks)")
@@ -66,11 +79,10 @@ def parse():
     ap.add_argument("--schedule", choices=["auto", "host", "host-async", "device"], default="auto",
                     help="where the bit-exact mode's PCG64 draw schedule is computed: host (synchronous native call), "
                          "host-async (pipelined native producer threads drawing ahead), device (csrc/devrng2.hip: no host "
-                         "threads); auto (default) = host-async when this rank's CPU share allows at least 6 producer "
-                         "workers, else device")
+                         "threads; opt-in); auto (default) = host-async sized to this rank's CPU share "
+                         "(ml2048_amd.shard.host_thread_plan)")
     ap.add_argument("--prefetch", type=int, default=0,
-                    help="draw the next rollout's host schedule on a worker thread (default 0: the async kernel "
-                         "launch already overlaps the host schedule of rollout k+1 with the GPU running rollout k)")
+                    help="draw the next rollout's host schedule on a worker thread (synchronous host schedule only)")
     return ap.parse_args()
 
 
@@ -148,15 +160,85 @@ def cpu_baseline(M: int, N: int, seed: int, seconds: float):
     }
 
 
+# ---- roofline bookkeeping ------------------------------------------------------------------------------------------
+def _inst_table():
+    """profiles/valu_insts.json: instructions per wave-step of the fused rollout kernel by (variant, pass), each
+    entry naming the committed rocprofv3 SQ-counter summary it was taken from."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "valu_insts.json")))
+    except Exception:
+        return {}
+
+
+def _traffic(key: str):
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if key in tj:
+            return tj[key]["bytes_per_launch"], tj[key].get("source")
+    except Exception:
+        pass
+    return None, None
+
+
+def rollout_roofline(M: int, N: int, avg_ms: float, masked: bool, traj: bool):
+    """VALU-issue roofline of k_rollout (fused) / HBM-write roofline of the trajectory-writing instantiation."""
+    waves = (M + 63) // 64
+    if traj:
+        alg = 54 * M * N  # the REPLAY_SPEC transitions this launch really writes
+        ach = alg / (avg_ms * 1e-3) / 1e9
+        tb, src = _traffic(f"k_rollout:M={M}:N={N}:traj")
+        return {"bound": "hbm", "kernel": "k_rollout<EXTRAS> (trajectory)", "achieved": ach, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tb, "traffic_source": src,
+                "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg,
+                "note": "algorithmic = the 54 B/board-step of REPLAY_SPEC transitions this launch writes"}
+    variant = "masked" if masked else "plain"
+    pass_ = "small" if M <= 131072 else "large"
+    ent = _inst_table().get(f"k_rollout:{variant}:{pass_}")
+    tb, src = _traffic(f"k_rollout:M={M}:N={N}")
+    r = {"bound": "valu_issue", "kernel": f"k_rollout<{variant}, {pass_}-M pass>", "unit": "G wave-instructions/s",
+         "peak": VALU_PEAK_GINST, "avg_launch_ms": avg_ms, "traffic": tb, "traffic_source": src,
+         "peak_note": "256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)"}
+    if ent:
+        valu = ent["valu_per_wave_step"]
+        ach = valu * waves * N / (avg_ms * 1e-3) / 1e9
+        r.update({"achieved": ach, "frac": ach / VALU_PEAK_GINST, "insts_per_wave_step": valu,
+                  "insts_source": ent["source"], "insts_measured_at": ent.get("measured_at")})
+        if ent.get("all_per_wave_step") and waves <= N_SIMD:
+            # one wave per SIMD (or fewer): every instruction of the lone wave, of any type, takes an issue slot of 4 cycles
+            r["lone_wave_frac"] = ent["all_per_wave_step"] * waves * N / (avg_ms * 1e-3) / 1e9 / \
+                (min(waves, N_SIMD) * CLOCK_GHZ / 4.0)
+        assert r["frac"] <= 1.0, r
+    else:
+        r.update({"achieved": None, "frac": None, "insts_per_wave_step": None,
+                  "note": f"no SQ-counter profile committed for k_rollout:{variant}:{pass_} (profiles/valu_insts.json)"})
+    eq = BYTES_PER_BOARD_STEP * M * N / (avg_ms * 1e-3) / 1e9
+    r["hbm_equivalent_99B"] = {"GB/s": eq, "x_of_8TBs": eq / HBM_PEAK_GBS,
+                               "note": "what N per-step launches would have to move for the same work; the fused kernel "
+                                       "keeps boards in registers (see traffic), so this is NOT a fraction of any roofline"}
+    return r
+
+
+def step_prepare_roofline(M: int, avg_ms: float, obs: bool, sampler: bool):
+    per = (BYTES_PER_BOARD_STEP_OBS if obs else BYTES_PER_BOARD_STEP) + 1  # + the terminated byte the fused kernel reads
+    if sampler and not obs:
+        per += 5  # next action 1 + log-prob 4 (already part of the 1128)
+    alg = per * M
+    ach = alg / (avg_ms * 1e-3) / 1e9
+    tb, src = _traffic(f"k_step_prepare:M={M}:obs={int(obs)}")
+    return {"bound": "hbm", "kernel": "k_step_prepare" + (" (+ one-hot, masked sampler)" if obs else " (+ sampler)"),
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tb,
+            "traffic_source": src, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg,
+            "bytes_per_board_step": per}
+
+
 def main():
     args = parse()
     import torch
 
     import ml2048_amd as amd
     from ml2048_amd import _lib
-
-    L = _lib.load()
     from ml2048_amd import build as hip_build
+    from ml2048_amd.shard import host_thread_plan, max_over_ranks
 
     if int(os.environ.get("LOCAL_RANK", "0")) == 0:
         hip_build.build()  # no-op when the in-tree library is up to date
@@ -164,6 +246,7 @@ def main():
         t_wait = time.time()
         while hip_build.is_stale() and time.time() - t_wait < 300:
             time.sleep(0.5)
+    L = _lib.load()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -189,54 +272,31 @@ def main():
             dist_mod.init_process_group(backend="gloo")
         dist = dist_mod
 
-    # host threads of the schedule producer: this rank's share of the box's CPUs (cgroup quota / ranks
-    # on this node), minus the Python thread, the stitcher and the HIP runtime's own threads; 8 workers draw a
-    # 128-step schedule in ~0.09 ms, which keeps the stream ahead of the ~0.11 ms rollout kernel
+    # host threads of the schedule producer: this rank's share of the node's CPUs (shard.host_thread_plan)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    plan = host_thread_plan(host_cpu_share(), local_world, args.schedule)
     if "ML2048_HOST_THREADS" not in os.environ:
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-        share = max(1, host_cpu_share() // max(1, local_world))
-        os.environ["ML2048_HOST_THREADS"] = str(max(1, min(8, share - 4)))
-    if args.schedule == "auto":
-        # the host stream needs ~6 workers to stay ahead of the 0.09 ms rollout kernel (4 workers: 0.149 ms per
-        # rollout; measured); on a rank with fewer CPUs the schedule drawn on the GPU (0.128 ms, no host threads) wins
-        args.schedule = "host-async" if int(os.environ["ML2048_HOST_THREADS"]) >= 6 else "device"
+        os.environ["ML2048_HOST_THREADS"] = str(plan["threads"])
+    args.schedule = plan["schedule"]
+    rank_info = {"rank": rank, "host_schedule": args.schedule, "ML2048_HOST_THREADS": int(os.environ["ML2048_HOST_THREADS"]),
+                 "cpus_per_rank": plan["cpus_per_rank"]}
 
     M, N, K, W = args.boards, args.env_steps, args.steps, args.warmup
-    # shard `rank` of a 2-level game: independent replica with its own seed (SURVEY 8e replica mode)
-    env = amd.VecGame(M, amd.reward_fn_normal, device=dev, idx_base=0, step_mapping=args.step_mapping,
-                      schedule=args.schedule)
-    env.reset(args.seed + rank)
-    pol = amd.RandomPolicy(seed=7 + rank, masked=bool(args.masked))
-    obs = torch.empty((M, 16, 4, 4), dtype=torch.float32, device=dev) if args.mode == "obs" else None
-    counter = [0]
-    kern_ms = []
+    masked = bool(args.masked) if args.masked is not None else args.mode == "obs"
 
-    traj = None
-    if args.mode == "fused-traj":  # every step's transition materialised: 54 B written per board-step
-        from ml2048_amd import train_ops
+    def new_timer():
+        tm = C.c_void_p()
+        _lib.check(L.ml2048_timer_create(C.byref(tm)), "timer_create")
+        return tm
 
-        traj = train_ops.new_buffers((N, M), dev, spec=train_ops.REPLAY_SPEC)
-
-    def bench_step(timed: bool):
-        if args.mode in ("fused", "fused-traj"):
-            tm = None
-            if timed:  # HIP event pair attached to the kernel's dispatch (hipExtLaunchKernel), on its stream
-                import ctypes as C
-                tm = C.c_void_p()
-                _lib.check(L.ml2048_timer_create(C.byref(tm)), "timer_create")
-            env.rollout(N, masked=bool(args.masked), act_seed=7 + rank, act_counter=counter[0], kernel_timer=tm,
-                        prefetch_next=bool(args.prefetch), trajectory=traj,
-                        finish_ids="deferred" if args.ids == "deferred" else True)
-            counter[0] += N
-            if tm is not None:
-                kern_ms.append(tm)
-        else:
-            for _ in range(N):
-                env.prepare_torch()
-                a, _ = pol.sample_actions_u8(env.valid_actions)
-                env.step_torch(a)
-                if obs is not None:
-                    env.onehot(out=obs)
+    def timers_avg_ms(timers):
+        vals = []
+        for tm in timers:
+            ms = C.c_float(0.0)
+            _lib.check(L.ml2048_timer_elapsed_ms(tm, C.byref(ms)), "timer_elapsed_ms")
+            vals.append(float(ms.value))
+            L.ml2048_timer_destroy(tm)
+        return sum(vals) / len(vals) if vals else None
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -244,108 +304,135 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(W):
-        bench_step(False)
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(K):
-        bench_step(k % max(1, args.event_every) == 0)
-    barrier()
-    dt = time.perf_counter() - t0
-    from ml2048_amd.shard import max_over_ranks
+    def measure(step_fn, k, w):
+        """w untimed + k timed bench steps, barrier + synchronize on both sides, max over ranks."""
+        for _ in range(w):
+            step_fn(False)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(k):
+            step_fn(i % max(1, args.event_every) == 0)
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0, dist)
 
-    dt = max_over_ranks(dt, dist)
+    # ---- workloads ----------------------------------------------------------------------------------------------
+    def make_fused(m, n, masked_, mode, schedule, seed_off=0):
+        env = amd.VecGame(m, amd.reward_fn_normal, device=dev, schedule=schedule)
+        env.reset(args.seed + rank + seed_off)
+        traj = None
+        if mode == "fused-traj":  # every step's transition materialised: 54 B written per board-step
+            from ml2048_amd import train_ops
 
-    total_board_steps = world * M * N * K
-    value = total_board_steps / dt
+            traj = train_ops.new_buffers((n, m), dev, spec=train_ops.REPLAY_SPEC)
+        counter = [0]
+        timers = []
 
-    # dominant kernel duration, HIP events on the launch stream
-    roofline = None
-    if args.mode in ("fused", "fused-traj") and kern_ms:
-        import ctypes as C
-        vals = []
-        for tm in kern_ms:
-            ms = C.c_float(0.0)
-            _lib.check(L.ml2048_timer_elapsed_ms(tm, C.byref(ms)), "timer_elapsed_ms")
-            vals.append(float(ms.value))
-            L.ml2048_timer_destroy(tm)
-        avg_ms = sum(vals) / len(vals)
-        # fused-traj: the 54 B/board-step of REPLAY_SPEC transitions are really written
-        alg_bytes = (54 if args.mode == "fused-traj" else BYTES_PER_BOARD_STEP) * M * N
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_rollout", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
-                    "algorithmic_bytes_per_launch": alg_bytes,
-                    "note": ("algorithmic = 99 B/board-step x M x N per launch (what N per-step launches must move); "
-                             "the fused kernel keeps boards in registers, so measured HBM traffic is far below it")
-                    if args.mode == "fused" else
-                    "algorithmic = the 54 B/board-step of REPLAY_SPEC transitions this launch really writes"}
+        def step(timed):
+            tm = new_timer() if timed else None
+            env.rollout(n, masked=masked_, act_seed=7 + rank, act_counter=counter[0], kernel_timer=tm,
+                        prefetch_next=bool(args.prefetch), trajectory=traj,
+                        finish_ids="deferred" if args.ids == "deferred" else True)
+            counter[0] += n
+            if tm is not None:
+                timers.append(tm)
+
+        return step, timers, env
+
+    def make_stepwise(m, n, masked_, obs_, seed_off=0):
+        """one ml2048_step_prepare launch per env step; the RandomPolicy draw for the next step comes out of it"""
+        env = amd.VecGame(m, amd.reward_fn_normal, device=dev)
+        env.reset(args.seed + rank + seed_off)
+        env.prepare_torch()
+        pol = amd.RandomPolicy(seed=7 + rank, masked=masked_)
+        obs_buf = torch.empty((m, 16, 4, 4), dtype=torch.float32, device=dev) if obs_ else None
+        cur = [pol.sample_actions_u8(env.valid_actions)[0]]
+        timers = []
+
+        def step(timed):
+            a = cur[0]
+            for j in range(n):
+                tm = None
+                if timed and j % 16 == 0:
+                    tm = new_timer()
+                    _lib.check(L.ml2048_timer_arm(tm), "timer_arm")
+                    timers.append(tm)
+                a = env.step_prepare_torch(a, sample=pol, onehot=obs_buf)["actions"]
+            cur[0] = a
+
+        return step, timers, env
+
+    def make_stepwise3(m, n, masked_):
+        env = amd.VecGame(m, amd.reward_fn_normal, device=dev, step_mapping=args.step_mapping)
+        env.reset(args.seed + rank)
+        pol = amd.RandomPolicy(seed=7 + rank, masked=masked_)
+
+        def step(timed):
+            for _ in range(n):
+                env.prepare_torch()
+                a, _ = pol.sample_actions_u8(env.valid_actions)
+                env.step_torch(a)
+
+        return step, [], env
+
+    if args.mode in ("fused", "fused-traj"):
+        step_fn, timers, env = make_fused(M, N, masked, args.mode, args.schedule)
+    elif args.mode in ("stepwise", "obs"):
+        step_fn, timers, env = make_stepwise(M, N, masked, args.mode == "obs")
     else:
-        # per-step API: time the step kernel alone over a few launches
-        evs = []
-        a, _ = pol.sample_actions_u8(env.valid_actions)
-        for _ in range(20):
-            env.prepare_torch()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            env.step_torch(a)
-            e1.record()
-            evs.append((e0, e1))
-        torch.cuda.synchronize(dev)
-        avg_ms = sorted(x.elapsed_time(y) for x, y in evs)[len(evs) // 2]
-        per = BYTES_PER_BOARD_STEP
-        achieved = per * M / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_step" if args.step_mapping == "lane" else "k_step_wave", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
-                    "algorithmic_bytes_per_launch": per * M}
-    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-    if roofline and os.path.exists(traffic_file):
-        try:
-            tj = json.load(open(traffic_file))
-            key = f"{roofline['kernel']}:M={M}:N={N if args.mode == 'fused' else 1}" + (":traj" if args.mode == "fused-traj" else "")
-            if key in tj:
-                roofline["traffic"] = tj[key]["bytes_per_launch"]
-                roofline["traffic_source"] = tj[key].get("source")
-        except Exception:
-            pass
+        step_fn, timers, env = make_stepwise3(M, N, masked)
+    dt = measure(step_fn, K, W)
+    value = world * M * N * K / dt
+    avg_ms = timers_avg_ms(timers)
+
+    if args.mode in ("fused", "fused-traj"):
+        roofline = rollout_roofline(M, N, avg_ms, masked, args.mode == "fused-traj")
+    elif args.mode in ("stepwise", "obs"):
+        roofline = step_prepare_roofline(M, avg_ms, args.mode == "obs", True)
+    else:
+        roofline = None  # three small launches per env step: host-launch-bound, no single dominant kernel to price
 
     extras = {}
     if rank == 0 and world == 1 and args.mode == "fused" and not args.no_extras:
-        # secondary: the same workload through the per-step API (what an RL loop with a policy uses)
-        env2 = amd.VecGame(M, amd.reward_fn_normal, device=dev)
-        env2.reset(args.seed)
-        pol2 = amd.RandomPolicy(seed=7, masked=bool(args.masked))
-
-        def stepwise():
-            for _ in range(N):
-                env2.prepare_torch()
-                a, _ = pol2.sample_actions_u8(env2.valid_actions)
-                env2.step_torch(a)
-
-        stepwise()
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
-            stepwise()
-        torch.cuda.synchronize(dev)
-        d1 = time.perf_counter() - t1
-        extras["stepwise"] = {"value": M * N * reps / d1, "unit": "board-steps/s",
-                              "us_per_env_step": d1 / (N * reps) * 1e6,
-                              "note": "per-step API: 3 kernel launches per env step (prepare, sample, step); host-launch-bound"}
-
-    if rank == 0 and world == 1 and args.mode == "fused" and not args.no_extras:
-        # secondary: the same fused workload in rocRAND spawn mode (no host PCG64 schedule; statistically the same
-        # game, bit-exact with the oracle's counter-based spawn, NOT with numba) - purely GPU-bound
+        saved_every = args.event_every
+        # (1) the same C2 workload, one launch per env step (what a policy-driven RL loop uses)
+        sfn, stm, _e = make_stepwise(M, N, masked, False, seed_off=100)
+        d1 = measure(sfn, 20, 3)
+        ms1 = timers_avg_ms(stm)
+        extras["stepwise"] = {"value": M * N * 20 / d1, "unit": "board-steps/s", "us_per_env_step": d1 / (N * 20) * 1e6,
+                              "workload": f"M={M} x N={N}, one ml2048_step_prepare launch per env step (step + re-deal + "
+                                          "next RandomPolicy draw), bit-exact spawn mode",
+                              "roofline": step_prepare_roofline(M, ms1, False, True)}
+        del sfn, _e
+        # (2) C3 = BASELINE.json configs[2]: M=262144, masked sampling + one-hot (M,16,4,4) f32 observation per env step
+        sfn, stm, _e = make_stepwise(262144, N, True, True, seed_off=200)
+        d1 = measure(sfn, 8, 2)
+        ms1 = timers_avg_ms(stm)
+        extras["c3_obs"] = {"value": 262144 * N * 8 / d1, "unit": "board-steps/s", "us_per_env_step": d1 / (N * 8) * 1e6,
+                            "workload": f"C3: M=262144 x N={N}, per env step ONE launch = step + re-deal + masked-uniform "
+                                        "sampling + one-hot (M,16,4,4) float32 observation into a torch tensor",
+                            "roofline": step_prepare_roofline(262144, ms1, True, True)}
+        del sfn, _e
+        # (3) the fused rollout at C4's per-GPU shard size (M=262144: the large-M pass of the kernel)
+        args.event_every = 4
+        sfn, stm, _e = make_fused(262144, N, masked, "fused", args.schedule, seed_off=300)
+        d1 = measure(sfn, 120, 20)
+        ms1 = timers_avg_ms(stm)
+        extras["fused_262144"] = {"value": 262144 * N * 120 / d1, "unit": "board-steps/s", "ms_per_step": d1 / 120 * 1e3,
+                                  "workload": f"M=262144 (BASELINE config 4's per-GPU shard) x N={N}, fused rollout",
+                                  "roofline": rollout_roofline(262144, N, ms1, masked, False)}
+        del sfn, _e
+        args.event_every = saved_every
+        # (4) the fused C2 workload in rocRAND spawn mode (no host PCG64 schedule; statistically the same game,
+        # bit-exact with the oracle's counter-based spawn, NOT with numba)
         env3 = amd.VecGame(M, amd.reward_fn_normal, device=dev, spawn="rocrand", spawn_seed=args.seed)
         env3.reset(args.seed)
         for _ in range(3):
-            env3.rollout(N, masked=bool(args.masked), act_seed=7)
+            env3.rollout(N, masked=masked, act_seed=7)
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         reps = 50
         for r in range(reps):
-            env3.rollout(N, masked=bool(args.masked), act_seed=7, act_counter=(r + 3) * N)
+            env3.rollout(N, masked=masked, act_seed=7, act_counter=(r + 3) * N)
         torch.cuda.synchronize(dev)
         d1 = time.perf_counter() - t1
         extras["rocrand_spawn_mode"] = {"value": M * N * reps / d1, "unit": "board-steps/s", "ms_per_step": d1 / reps * 1e3,
@@ -356,17 +443,32 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(M, N, args.seed, args.cpu_seconds)
 
+    per_rank = [rank_info]
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rank_info)
+        per_rank = gathered
+
     if rank == 0:
+        tag = "C2: " if (M, N, args.mode, masked) == (65536, 128, "fused", False) else \
+              "C3: " if (M, args.mode, masked) == (262144, "obs", True) else ""
+        what = {"fused": "one fused rollout launch per bench step",
+                "fused-traj": "one fused rollout launch per bench step, every transition written (REPLAY_SPEC)",
+                "stepwise": "one ml2048_step_prepare launch per env step (step + re-deal + next RandomPolicy draw)",
+                "obs": "one ml2048_step_prepare launch per env step incl. masked sampling + one-hot (M,16,4,4) f32 observation",
+                "stepwise3": "reference-shaped per-step API: prepare, sample, step launches per env step"}[args.mode]
         line = {
             "metric": "env board-steps/sec (M boards x N steps), bit-exact vs game_numba semantics",
             "value": value, "unit": "board-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"C2: M={M} boards/GPU x N={N} random-action env steps per bench step "
-                                   f"({'masked' if args.masked else 'unmasked'} uniform actions sampled on device, "
-                                   f"table spawn = bit-exact mode), mode={args.mode}",
+            "config": {"workload": f"{tag}M={M} boards/GPU x N={N} random-action env steps per bench step "
+                                   f"({'masked' if masked else 'unmasked'} uniform actions sampled on device, "
+                                   f"table spawn = bit-exact mode), {what}",
                        "boards_per_gpu": M, "env_steps_per_step": N, "mode": args.mode, "sharding": f"replicas x{world}",
-                       "host_schedule": args.schedule, "id_scan": args.ids, "spawn": "table (bit-exact with the reference's PCG64 tables)"},
+                       "host_schedule": args.schedule, "ML2048_HOST_THREADS": int(os.environ["ML2048_HOST_THREADS"]),
+                       "per_rank": per_rank, "id_scan": args.ids,
+                       "spawn": "table (bit-exact with the reference's PCG64 tables)"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         line.update(extras)

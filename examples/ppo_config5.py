@@ -209,6 +209,9 @@ def main():
     ap.add_argument("--use", type=int, default=2)
     ap.add_argument("--seed", type=int, default=20241008)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--fused-step", type=int, default=1,
+                    help="one env launch per step (ml2048_step_prepare: step + transition record into the replay "
+                         "slices + re-deal + terminated-games histogram) instead of prepare / step / record / histogram")
     ap.add_argument("--fused-front", type=int, default=1,
                     help="no-grad encoder passes (rollout policy, GAE critic passes) through ml2048_encoder_front")
     args = ap.parse_args()
@@ -225,6 +228,11 @@ def main():
     net_eval = ActorCritic().to(dev)
     buffers = train_ops.new_buffers((U, S, M), dev)
     stats = amd.RunnerStats()
+    # ml2048_step_out pointed at the [game] slices of the replay buffers, one dict per (use, step)
+    step_outs = [[{"prev_state": buffers["state"][u, s], "prev_valid_actions": buffers["valid_actions"][u, s],
+                   "reward": buffers["reward"][u, s], "state": buffers["next_state"][u, s],
+                   "valid_actions": buffers["next_valid_actions"][u, s], "step": buffers["step"][u, s],
+                   "terminated": buffers["terminated"][u, s]} for s in range(S)] for u in range(U)]
     obs = torch.empty((M, 16, 4, 4), dtype=torch.float32, device=dev)
     log = []
     env_time = net_time = train_time = 0.0
@@ -235,18 +243,39 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         t_env = 0.0
-        for si in range(S):  # VecRunner.step_once, runner.py:74-109, with everything on device
+        if args.fused_step:
+            # VecRunner.step_once (runner.py:74-109) with ONE env launch per step: the policy acts on the live
+            # (post-prepare) state; ml2048_step_prepare steps, writes the transition straight into this step's replay
+            # slices (Trainer.on_stepped's nine copies, run_train3.py:125-155), adds the finished games to the
+            # histogram and re-deals them - the state the next policy call observes
             te = time.perf_counter()
-            env.prepare_torch()
-            if not args.fused_front:
-                env.onehot(out=obs)
+            if not env._prepared:
+                env.prepare_torch()
+                if not args.fused_front:
+                    env.onehot(out=obs)
             t_env += time.perf_counter() - te
-            a, lp = net_eval.act(obs, env.valid_actions.bool(), board=env.board if args.fused_front else None)
-            te = time.perf_counter()
-            res = env.step_torch(a.to(torch.uint8))
-            train_ops.record_transition(env, a, lp, buffers, ui, si)
-            stats.on_stepped(env, res, a, lp)
-            t_env += time.perf_counter() - te
+            for si in range(S):
+                a, lp = net_eval.act(obs, env.valid_actions.bool(), board=env.board if args.fused_front else None)
+                te = time.perf_counter()
+                a8 = a.to(torch.uint8)
+                buffers["action"][ui, si].copy_(a8.view(torch.int8))
+                buffers["action_log_prob"][ui, si].copy_(lp)
+                env.step_prepare_torch(a8, out=step_outs[ui][si], hist=stats.device_counts(env),
+                                       onehot=None if args.fused_front else obs)
+                t_env += time.perf_counter() - te
+        else:
+            for si in range(S):  # the reference-shaped loop: prepare / step / record / histogram launches
+                te = time.perf_counter()
+                env.prepare_torch()
+                if not args.fused_front:
+                    env.onehot(out=obs)
+                t_env += time.perf_counter() - te
+                a, lp = net_eval.act(obs, env.valid_actions.bool(), board=env.board if args.fused_front else None)
+                te = time.perf_counter()
+                res = env.step_torch(a.to(torch.uint8))
+                train_ops.record_transition(env, a, lp, buffers, ui, si)
+                stats.on_stepped(env, res, a, lp)
+                t_env += time.perf_counter() - te
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         n_use = min(epoch + 1, U)
@@ -273,6 +302,7 @@ def main():
         log.append(entry)
         print(json.dumps(entry), flush=True)
     summary = {"config": f"C5: games={M} steps={S} use={U} reward=improved", "epochs": args.epochs,
+               "fused_step": bool(args.fused_step), "fused_front": bool(args.fused_front),
                "env_steps_per_s_in_loop": M * S * args.epochs / (env_time + net_time),
                "env_host_time_share_of_rollout": env_time / (env_time + net_time),
                "epoch_s": (env_time + net_time + train_time) / args.epochs,

@@ -289,7 +289,7 @@ int64_t ml2048_rollout_flag_words(int64_t M);
 int64_t ml2048_rollout_scratch_ints(int64_t M, int32_t N);
 
 /*
- * Measurement only: a HIP event pair attached to the dispatch of the next ml2048_rollout* launch made
+ * Measurement only: a HIP event pair attached to the dispatch of the next ml2048_rollout* / ml2048_step_prepare launch made
  * by the calling thread (hipExtLaunchKernel start/stop events), i.e. the kernel's own duration as
  * rocprofv3 reports it, without the marker packets that events recorded around a launch add.
  * create -> arm (one-shot) -> launch -> elapsed_ms (synchronises on the stop event) -> destroy.

@@ -1649,6 +1649,19 @@ void ml2048_timer_destroy(void *timer) {
     delete t;
 }
 
+} // extern "C"
+// the armed one-shot timer, for launches made by the other kernel files (step_prepare.hip)
+__attribute__((visibility("hidden"))) bool ml2048_internal_take_timer(hipEvent_t *start, hipEvent_t *stop) {
+    ml2048_timer_impl *t = g_armed_timer;
+    g_armed_timer = nullptr;
+    if (!t) return false;
+    t->used = true;
+    *start = t->start;
+    *stop = t->stop;
+    return true;
+}
+extern "C" {
+
 // largest M that runs the max-ilp build of the plain rollout kernels (see ml2048_plain_launch); ML2048_PLAIN_ILP_MAX
 // overrides it for A/B runs
 static int64_t plain_ilp_max_boards() {

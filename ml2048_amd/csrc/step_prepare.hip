@@ -29,6 +29,7 @@
 // (terminated read) + what the caller asks for: one-hot 1 024 B, int64 128 B, next action 1 + log-prob 4 B,
 // ml2048_step_out up to 74 B; re-deals (< 1 % of boards per step) rewrite their 58-byte record.  No MFMA: byte work.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/ml2048_hip.h"
@@ -42,6 +43,7 @@ using namespace ml2048::dev;
 __attribute__((visibility("hidden"))) int ml2048_internal_fail(int code, const char *fmt, ...);
 __attribute__((visibility("hidden"))) int ml2048_internal_check_state(int64_t M, const ml2048_state *st);
 __attribute__((visibility("hidden"))) uint64_t ml2048_internal_two_threshold(double two_prob);
+__attribute__((visibility("hidden"))) bool ml2048_internal_take_timer(hipEvent_t *start, hipEvent_t *stop);
 
 namespace {
 
@@ -368,13 +370,17 @@ int ml2048_step_prepare(void *stream, const ml2048_step_prepare_args *a) {
     const uint64_t thr = ml2048_internal_two_threshold(a->two_prob);
     const dim3 grid((unsigned)g.nblk), block(kBlk);
     hipStream_t s = (hipStream_t)stream;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; // ml2048_timer_arm: events attached to this very dispatch
+    (void)ml2048_internal_take_timer(&ev0, &ev1);
+#define ML_SP(F, S) hipExtLaunchKernelGGL((k_step_prepare<F, S>), grid, block, 0, s, ev0, ev1, 0, *a, g.R, thr)
     if (fast) {
-        if (g.R == 1) hipLaunchKernelGGL((k_step_prepare<true, true>), grid, block, 0, s, *a, g.R, thr);
-        else hipLaunchKernelGGL((k_step_prepare<true, false>), grid, block, 0, s, *a, g.R, thr);
+        if (g.R == 1) ML_SP(true, true);
+        else ML_SP(true, false);
     } else {
-        if (g.R == 1) hipLaunchKernelGGL((k_step_prepare<false, true>), grid, block, 0, s, *a, g.R, thr);
-        else hipLaunchKernelGGL((k_step_prepare<false, false>), grid, block, 0, s, *a, g.R, thr);
+        if (g.R == 1) ML_SP(false, true);
+        else ML_SP(false, false);
     }
+#undef ML_SP
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ml2048_internal_fail((int)e, "ml2048_step_prepare: %s", hipGetErrorString(e));
     return 0;

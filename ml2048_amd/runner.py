@@ -138,34 +138,37 @@ class RunnerStats:
         self.counts = np.zeros((20,), dtype=np.int32)
         self.terminated_count = 0
         self._dev: torch.Tensor | None = None
-        self._term: torch.Tensor | None = None
 
     def reset(self) -> None:
         self.counts.fill(0)
         self.terminated_count = 0
         if self._dev is not None:
             self._dev.zero_()
-            self._term.zero_()
 
-    def on_stepped(self, game: VecGame, result, actions, action_log_probs) -> None:
+    def device_counts(self, game: VecGame) -> torch.Tensor:
+        """The int32[20] device accumulator (pass it as `VecGame.step_prepare_torch(hist=...)`: the fused step adds
+        the finished games' max tiles itself, no extra launch)."""
         if self._dev is None:
             self._dev = torch.zeros((20,), dtype=torch.int32, device=game.device)
-            self._term = torch.zeros((1,), dtype=torch.int64, device=game.device)
+        return self._dev
+
+    def on_stepped(self, game: VecGame, result, actions, action_log_probs) -> None:
         # _update_count(counts, result["state"], result["terminated"]), runner.py:120-136, on the result's own arrays
         # (the live state in the per-step mode; the runner's outcome buffers in the fused mode)
+        acc = self.device_counts(game)
         state, term = result["state"], result["terminated"]
         with game._dev_ctx():
             _lib.check(game._L.ml2048_hist_maxcell(game._stream(), game._size, state.data_ptr(), term.data_ptr(),
-                                                   self._dev.data_ptr()), "hist")
-        self._term += term.sum()
+                                                   acc.data_ptr()), "hist")
 
     def sync(self) -> None:
-        """Fold the device accumulators into `counts` / `terminated_count` (one small D2H)."""
+        """Fold the device accumulator into `counts` / `terminated_count` (one small D2H).  Every terminated game is
+        counted in exactly one bin (runner.py:131-136, :162), so the terminated count is the histogram's total."""
         if self._dev is not None:
-            self.counts += self._dev.cpu().numpy()
-            self.terminated_count += int(self._term.item())
+            delta = self._dev.cpu().numpy()
+            self.counts += delta
+            self.terminated_count += int(delta.sum())
             self._dev.zero_()
-            self._term.zero_()
 
     def summary(self) -> list[tuple]:
         """[(tile value, games, share)] from the largest tile down, skipping empty bins

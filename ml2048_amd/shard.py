@@ -32,6 +32,29 @@ class ShardPlan:
         return ShardPlan(rank, world, boards, idx_base, base_seed + rank)
 
 
+def host_thread_plan(cpu_share: int, local_world: int, requested: str = "auto") -> dict:
+    """How one rank of `local_world` ranks on a node with `cpu_share` usable CPUs produces the bit-exact mode's
+    PCG64 draw schedule: {"threads": producer workers (ML2048_HOST_THREADS), "schedule": VecGame(schedule=...),
+    "cpus_per_rank": ...}.
+
+    Every rank runs a Python thread, the HIP runtime's helper threads and (host-async) one stitcher besides the
+    workers, hence `share - 4`; more than 8 workers crowd those out (measured: 10-14 workers are slower than 8).
+    Measured per 128-step schedule on the GPU box's EPYC 9575F: 0.48 / 0.26 / 0.13 / 0.10 / 0.074 ms with
+    1 / 2 / 4 / 6 / 8 workers, against a 0.087 ms rollout kernel at 65 536 boards - so fewer than 6 workers make the
+    run host-bound, but it stays correct and pipelined.  "auto" never picks the schedule drawn on the GPU
+    (`schedule="device"`, 0.128 ms per rollout with no host threads at all): that path is opt-in.  With fewer than
+    3 CPUs per rank there is no room for producer threads: the synchronous native call."""
+    per_rank = max(1, int(cpu_share) // max(1, int(local_world)))
+    threads = max(1, min(8, per_rank - 4))
+    if requested != "auto":
+        schedule = requested
+    elif per_rank < 3:
+        schedule = "host"
+    else:
+        schedule = "host-async"
+    return {"threads": threads, "schedule": schedule, "cpus_per_rank": per_rank}
+
+
 def gather_counts(counts, dist=None) -> np.ndarray:
     """Sum a small integer vector (max-tile histogram, terminated count, ...) over all ranks.
     dist: the torch.distributed module of an initialised process group, or None for one rank."""

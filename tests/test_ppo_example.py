@@ -28,3 +28,35 @@ def test_ppo_loop_runs_and_env_is_deterministic(tmp_path):
     assert a["log"][0]["top_tiles"] == b["log"][0]["top_tiles"]
     for e in a["log"]:
         assert all(isinstance(x, float) for x in e["losses"])
+
+
+@pytest.mark.gpu
+def test_ppo_config5_at_its_stated_size(tmp_path):
+    """BASELINE config 5 at full size (run_train3.py:62-89, :285-302 shapes: M=2048 games, N=64 steps, use=2,
+    reward_fn_improved), two epochs: finite losses, the env side deterministic under a fixed seed, and the
+    one-launch-per-step loop (ml2048_step_prepare writing straight into the replay slices) collecting the same
+    transitions as the reference-shaped prepare / step / record loop."""
+    def run(tag, *extra):
+        out = tmp_path / f"{tag}.json"
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "ppo_config5.py"), "--epochs", "2",
+                            "--games", "2048", "--steps", "64", "--json", str(out), *extra],
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.load(open(out))
+
+    a, b, c = run("fused_a"), run("fused_b"), run("per_step", "--fused-step", "0")
+    for r in (a, b, c):
+        assert r["summary"]["config"].startswith("C5: games=2048 steps=64 use=2") and len(r["log"]) == 2
+        for e in r["log"]:
+            assert all(isinstance(x, float) and x == x and abs(x) < 1e12 for x in e["losses"]), e["losses"]
+    print("C5 env-steps/s inside the rollout loop: fused step %.3g, per-step launches %.3g" %
+          (a["summary"]["env_steps_per_s_in_loop"], c["summary"]["env_steps_per_s_in_loop"]))
+    assert a["summary"]["fused_step"] and not c["summary"]["fused_step"]
+    # same seed -> same initial weights -> same actions -> same games: epoch 0 is reproducible ...
+    assert a["log"][0]["mean_score"] == b["log"][0]["mean_score"] and a["log"][0]["top_tiles"] == b["log"][0]["top_tiles"]
+    assert a["log"][0]["terminated"] == b["log"][0]["terminated"]
+    # ... and the fused step plays and records the same games as the separate launches (the losses come from the same
+    # replay contents; tolerance: the float summation order of torch's reductions, not the environment)
+    assert a["log"][0]["terminated"] == c["log"][0]["terminated"]
+    for x, y in zip(a["log"][0]["losses"], c["log"][0]["losses"]):
+        assert abs(x - y) <= 1e-3 * max(1.0, abs(x), abs(y)), (a["log"][0]["losses"], c["log"][0]["losses"])

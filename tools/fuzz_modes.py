@@ -7,6 +7,7 @@ import sys
 import time
 
 import numpy as np
+import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import ml2048_amd as amd
@@ -33,8 +34,21 @@ while time.time() - t0 < budget:
         e.reset(seed)
     counter = 0
     for _ in range(int(rng.integers(5, 25))):
-        op = rng.integers(0, 10)
-        if op < 6:  # fused rollout: often the same length again (chained upload of the schedule taken ahead),
+        op = rng.integers(0, 12)
+        if op >= 10:  # fused one-launch steps (step + following prepare) on the three envs, the per-step pair on the fourth
+            k = int(rng.choice([1, 2, 5, 130]))
+            for _ in range(k):
+                a = rng.integers(0, 4, size=M).astype(np.uint8)
+                at = torch.from_numpy(a).cuda()
+                for e in envs.values():
+                    if not e._prepared:
+                        e.prepare_torch()
+                    e.step_prepare_torch(at)
+                if not step_env._prepared:
+                    step_env.prepare_torch()
+                step_env.step_torch(at)
+                step_env.prepare_torch()
+        elif op < 6:  # fused rollout: often the same length again (chained upload of the schedule taken ahead),
             # with the id scan inline or deferred, sometimes with per-step digests (drops the look-ahead)
             n = last_n if rng.random() < 0.5 else int(rng.choice([1, 2, 7, 33, 64, 128, 200]))
             last_n = n

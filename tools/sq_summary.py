@@ -1,7 +1,7 @@
 """Summarise rocprofv3 --pmc SQ_* passes for the fused rollout kernel: counter totals per launch and per
 wave-step (one wave advancing its 64 boards by one env step).
 
-    python tools/sq_summary.py <pass dir> [<pass dir> ...]      (M = 65536, N = 128 assumed: bench.py default)
+    python tools/sq_summary.py [--M boards] [--N steps] <pass dir> [<pass dir> ...]   (default M = 65536, N = 128)
 """
 import collections
 import csv
@@ -11,7 +11,15 @@ import statistics as st
 import sys
 
 M, N = 65536, 128
-waves = M // 64
+argv = sys.argv[1:]
+while argv and argv[0] in ("--M", "--N"):
+    if argv[0] == "--M":
+        M = int(argv[1])
+    else:
+        N = int(argv[1])
+    argv = argv[2:]
+sys.argv[1:] = argv
+waves = (M + 63) // 64
 acc = collections.defaultdict(list)
 dur = []
 for d in sys.argv[1:]:
@@ -21,7 +29,8 @@ for d in sys.argv[1:]:
                 continue
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-out = {"kernel": "k_rollout<0,false,false>", "M": M, "N": N, "waves": waves,
+names = set()
+out = {"kernel": "k_rollout", "M": M, "N": N, "waves": waves,
        "launch_us_under_pmc": st.median(dur) / 1e3 if dur else None, "counters": {}}
 for name, vals in sorted(acc.items()):
     v = st.median(vals)
