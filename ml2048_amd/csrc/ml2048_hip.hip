@@ -1034,16 +1034,39 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                 //      dtypes (replay.py:10-20), i.e. what N x ml2048_record_transition would write
                 if (EXTRAS && live) {
                     const int64_t o = (int64_t)t * M + i;
-                    if (traj.state) reinterpret_cast<uint4 *>(traj.state)[o] = make_uint4(prev_board.r[0], prev_board.r[1], prev_board.r[2], prev_board.r[3]);
-                    if (traj.next_state) reinterpret_cast<uint4 *>(traj.next_state)[o] = make_uint4(s.board.r[0], s.board.r[1], s.board.r[2], s.board.r[3]);
-                    if (traj.valid_actions) reinterpret_cast<uint32_t *>(traj.valid_actions)[o] = prev_valid;
-                    if (traj.next_valid_actions) reinterpret_cast<uint32_t *>(traj.next_valid_actions)[o] = s.valid;
-                    if (traj.action) traj.action[o] = (int8_t)action;
-                    if (traj.action_log_prob) traj.action_log_prob[o] = neg_log_count(cnt);
-                    if (traj.reward) traj.reward[o] = s.reward;
-                    if (traj.step) traj.step[o] = s.step;
-                    if (traj.terminated) traj.terminated[o] = s.terminated != 0;
+                    // written once, read by another kernel much later: non-temporal stores (ML2048_TRAJ_NT=0: A/B) -
+                    // same box, 1 M boards: 1.43-1.56 ms vs 1.55-1.94 ms per launch; 262 144: 428 vs 456 us; C2: 167 vs 175 us.
+                    // Measured and dropped on the same boxes (profiles/r02_f_traj_ab.log): the epoch's permutation table
+                    // staged in LDS so that the loop holds no vector load (whose vmcnt wait also covers the previous
+                    // step's stores on gfx9): +10 % at C2 (13 exposed refills), +2 % at 1 M; the seven narrow fields
+                    // staged in LDS and written as one full-width store per field per workgroup (15 store instructions
+                    // per workgroup-step instead of 36, one barrier per step): +30 % at C2, +11 % at 262 144, +-0 at 1 M.
+#if !defined(ML2048_TRAJ_NT) || ML2048_TRAJ_NT
+#define ML_TSTORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define ML_TSTORE(ptr, val) (*(ptr) = (val))
+#endif
+                    if (traj.state) {
+                        uint32_t *d = reinterpret_cast<uint32_t *>(traj.state) + 4 * o;
+                        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                        const v4u q = {prev_board.r[0], prev_board.r[1], prev_board.r[2], prev_board.r[3]};
+                        ML_TSTORE(reinterpret_cast<v4u *>(d), q);
+                    }
+                    if (traj.next_state) {
+                        uint32_t *d = reinterpret_cast<uint32_t *>(traj.next_state) + 4 * o;
+                        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                        const v4u q = {s.board.r[0], s.board.r[1], s.board.r[2], s.board.r[3]};
+                        ML_TSTORE(reinterpret_cast<v4u *>(d), q);
+                    }
+                    if (traj.valid_actions) ML_TSTORE(reinterpret_cast<uint32_t *>(traj.valid_actions) + o, prev_valid);
+                    if (traj.next_valid_actions) ML_TSTORE(reinterpret_cast<uint32_t *>(traj.next_valid_actions) + o, s.valid);
+                    if (traj.action) ML_TSTORE(traj.action + o, (int8_t)action);
+                    if (traj.action_log_prob) ML_TSTORE(traj.action_log_prob + o, neg_log_count(cnt));
+                    if (traj.reward) ML_TSTORE(traj.reward + o, s.reward);
+                    if (traj.step) ML_TSTORE(traj.step + o, s.step);
+                    if (traj.terminated) ML_TSTORE(traj.terminated + o, (uint8_t)(s.terminated != 0));
                 }
+#undef ML_TSTORE
                 if (EXTRAS && digests_out) {
                     if (merged_stale) {
                         merge_buckets(mexp_first, mexp_second, s.merged);

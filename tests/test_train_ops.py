@@ -92,19 +92,22 @@ def test_record_transition_equals_on_stepped_copies():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("masked", [True, False])
-def test_fused_trajectory_equals_stepwise_recording(masked):
+@pytest.mark.parametrize("masked,M,N", [(True, 5000, 70), (False, 5000, 70),
+                                        (True, 4096, 33), (False, 65536, 9),
+                                        (False, 1023, 40), (True, 255, 17)])
+def test_fused_trajectory_equals_stepwise_recording(masked, M, N):
     """rollout(trajectory=...) writes, in one launch, what N x {prepare; sample; step;
-    record_transition} write."""
+    record_transition} write (sizes with full, partial and unaligned tail workgroups; every output byte checked)."""
     import ml2048_amd as amd
     from ml2048_amd import train_ops
 
-    M, N = 5000, 70
     a = amd.VecGame(M, amd.reward_fn_improved)
     b = amd.VecGame(M, amd.reward_fn_improved)
     a.reset(21)
     b.reset(21)
     traj = train_ops.new_buffers((N, M), a.device, spec=train_ops.REPLAY_SPEC)
+    for v in traj.values():
+        v.view(torch.uint8).fill_(0xA5)  # every byte must be written by the kernel
     a.rollout(N, masked=masked, act_seed=6, act_counter=50, trajectory=traj)
     ref = train_ops.new_buffers((1, N, M), b.device, spec=train_ops.REPLAY_SPEC)
     pol = amd.RandomPolicy(seed=6, masked=masked)
@@ -115,5 +118,26 @@ def test_fused_trajectory_equals_stepwise_recording(masked):
         b.step_torch(act)
         train_ops.record_transition(b, act, lp, ref, 0, t)
     for k in train_ops.REPLAY_SPEC:
-        assert torch.equal(traj[k], ref[k][0]), k
+        assert torch.equal(traj[k].view(torch.uint8), ref[k][0].view(torch.uint8)), k
     assert a._data.tobytes() == b._data.tobytes()
+
+
+@pytest.mark.gpu
+def test_fused_trajectory_with_missing_fields():
+    """Any subset of the REPLAY_SPEC fields may be requested (NULL pointers are skipped)."""
+    import ml2048_amd as amd
+    from ml2048_amd import train_ops
+
+    M, N = 2048, 25
+    full = train_ops.new_buffers((N, M), "cuda", spec=train_ops.REPLAY_SPEC)
+    a = amd.VecGame(M)
+    a.reset(3)
+    a.rollout(N, masked=True, act_seed=1, trajectory=full)
+    for keep in (("reward", "terminated"), ("state", "action"), ("next_valid_actions", "step", "action_log_prob")):
+        part = {k: torch.zeros_like(v) for k, v in full.items() if k in keep}
+        b = amd.VecGame(M)
+        b.reset(3)
+        b.rollout(N, masked=True, act_seed=1, trajectory=part)
+        for k in keep:
+            assert torch.equal(part[k], full[k]), (keep, k)
+        assert a.digest() == b.digest()
