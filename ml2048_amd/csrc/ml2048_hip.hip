@@ -425,6 +425,9 @@ __global__ __launch_bounds__(kPrepBlock) void k_prep_deal(ml2048_state st, int64
 // look-back window, M <= 65 536): with more, all workgroups start at once, every one of them walks back
 // window by window to the few prefixes that exist yet (O(blocks^2 / 64) probes; measured 297 us vs 122 us per
 // env step at 4 M boards), and the three bandwidth-bound launches win again.
+// The status accesses are RELAXED device-scope atomics: the word itself (tag, kind, count) is all that a reader
+// consumes, and a release store / acquire load here means an L2 write-back / an L1 invalidate per access
+// (step_prepare.hip measured that at 36 vs 15 us per launch).
 constexpr int kPrepFusedBlocks = 64;
 constexpr unsigned long long kStAggregate = 1ull << 32, kStPrefix = 2ull << 32;
 
@@ -450,20 +453,21 @@ __global__ __launch_bounds__(kPrepBlock) void k_prep_fused(ml2048_state st, int6
     if (wave == 0) { // the look-back is done by one wavefront: 64 predecessors per probe
         int tot = 0;
         for (int w = 0; w < kPrepBlock / 64; ++w) tot += wave_cnt[w];
-        const int gc0 = *game_count; // before this workgroup publishes anything
+        const int gc0 = *game_count; // before this workgroup publishes anything:
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // (the load has returned before the relaxed store below issues)
         const unsigned long long tag = (unsigned long long)epoch << 34;
         const int b = (int)blockIdx.x;
         int excl = 0;
         if (b == 0) {
-            if (lane == 0) __hip_atomic_store(status, tag | kStPrefix | (uint32_t)tot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(status, tag | kStPrefix | (uint32_t)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            if (lane == 0) __hip_atomic_store(status + b, tag | kStAggregate | (uint32_t)tot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(status + b, tag | kStAggregate | (uint32_t)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (int hi = b - 1; hi >= 0;) { // window = predecessors hi, hi-1, ..., hi-63 (lane 0 = nearest)
                 const int j = hi - lane;
                 unsigned long long v = 0;
                 bool ready = true;
                 if (j >= 0) {
-                    v = __hip_atomic_load(status + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    v = __hip_atomic_load(status + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ready = (v >> 34) == epoch && (v & (3ull << 32)) != 0;
                 }
                 const unsigned long long prefix_lanes = __ballot(j >= 0 && ready && (v & kStPrefix));
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(kPrepBlock) void k_prep_fused(ml2048_state st, int6
                 excl += val;
                 hi -= run;
             }
-            if (lane == 0) __hip_atomic_store(status + b, tag | kStPrefix | (uint32_t)(excl + tot), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(status + b, tag | kStPrefix | (uint32_t)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (lane == 0) {
             s_excl = excl;

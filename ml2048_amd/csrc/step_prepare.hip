@@ -21,6 +21,10 @@
 // sampling), and only then sums the words of the workgroups below it (<= 1023 words, 4 per thread, one L2 round
 // trip: no serial look-back chain).  With <= 1024 workgroups of 256 threads all of them are resident at once and
 // workgroups are dispatched in index order, so waiting for lower indices cannot deadlock.
+// (Measured and dropped: up to 65 536 workgroups - one pass for any M up to 16.7 M boards - with a two-level exchange,
+// own group of 64 + totals of the lower groups: the words read grow with workgroups^2 / 128 and every one is a
+// device-scope access; 4 M boards 180 vs 129 us per launch, 16.7 M 753 vs 490-690 us, and the second barrier costs
+// C3 47.9 vs 44.9 us.)
 // The epoch lives in device memory next to the status words (the last workgroup advances it once all others have
 // published, i.e. have read it), so the launch can be captured in a hipGraph and replayed.
 //
@@ -31,6 +35,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/ml2048_hip.h"
 #include "board_ops.hpp"
@@ -58,7 +63,12 @@ struct Geometry {
 };
 Geometry geometry(int64_t M) {
     const int64_t waves = cdiv(M, 64);
-    int64_t R = cdiv(cdiv(waves, kBlk / 64), kMaxBlocks);
+    int64_t max_blocks = kMaxBlocks;
+    if (const char *e = getenv("ML2048_SP_MAX_BLOCKS")) { // tests: exercise the multi-pass form at small M
+        const long v = atol(e);
+        if (v >= 1 && v < kMaxBlocks) max_blocks = v;
+    }
+    int64_t R = cdiv(cdiv(waves, kBlk / 64), max_blocks);
     if (R < 1) R = 1;
     return {(int)R, (int)cdiv(waves, (kBlk / 64) * R)};
 }
@@ -128,29 +138,56 @@ __global__ __launch_bounds__(kBlk) void k_step_prepare(const ml2048_step_prepare
     uint32_t term = 0;     // SINGLE: terminated after the step (of a live lane)
     bool live = false;
     int my_cnt = 0;        // wave-uniform: boards of this wave to re-deal
+    // one iteration's inputs; the multi-pass form requests iteration r + 1 before it works on r (a wave that walks its
+    // boards 64 at a time has one request wave in flight otherwise: 16 M boards 491 us per launch vs 332 + 115 us for
+    // the separate step and prepare kernels)
+    struct Inputs {
+        Board board;
+        uint32_t valid, t_before, action, perm[4], stale_merged[4];
+        int32_t step, id_before;
+        float score, stale_reward;
+    };
+    auto load_inputs = [&](int r, Inputs &x) __attribute__((always_inline)) {
+        const int64_t i0 = wbase + (int64_t)r * 64 + lane;
+        const int64_t i = i0 < M ? i0 : M - 1; // tail lanes shadow the last board: loads only, no stores
+        x.board = load_board(st.board, i);
+        x.valid = reinterpret_cast<const uint32_t *>(st.valid)[i];
+        x.step = st.step[i];
+        x.score = st.score[i];
+        x.t_before = st.terminated[i];
+        x.action = load_action(a.actions, a.action_dtype, i);
+        x.perm[0] = x.perm[1] = x.perm[2] = x.perm[3] = 0;
+        if (!FAST) load_perm_row(a.randperm_step, a.row_base_step + a.idx_base + i, x.perm);
+        // what an invalid move leaves untouched (H3) is still part of the step's outcome
+        x.stale_merged[0] = x.stale_merged[1] = x.stale_merged[2] = x.stale_merged[3] = 0;
+        x.stale_reward = 0.0f;
+        x.id_before = 0;
+        if (a.out.merged) {
+            const uint4 m = reinterpret_cast<const uint4 *>(st.merged)[i];
+            x.stale_merged[0] = m.x; x.stale_merged[1] = m.y; x.stale_merged[2] = m.z; x.stale_merged[3] = m.w;
+        }
+        if (a.out.reward) x.stale_reward = st.reward[i];
+        if (a.out.id) x.id_before = st.id[i];
+    };
+    Inputs in;
+    if (wbase < M) load_inputs(0, in);
     for (int r = 0; r < R; ++r) {
         const int64_t i0 = wbase + (int64_t)r * 64 + lane;
         if (wbase + (int64_t)r * 64 >= M) break; // wave-uniform
         live = i0 < M;
-        const int64_t i = live ? i0 : M - 1; // tail lanes shadow the last board: loads only, no stores
-        s.board = load_board(st.board, i);
-        s.valid = reinterpret_cast<const uint32_t *>(st.valid)[i];
-        s.step = st.step[i];
-        s.score = st.score[i];
-        const uint32_t t_before = st.terminated[i];
-        const uint32_t action = load_action(a.actions, a.action_dtype, i);
-        uint32_t perm[4] = {0, 0, 0, 0};
-        if (!FAST) load_perm_row(a.randperm_step, a.row_base_step + a.idx_base + i, perm);
-        // what an invalid move leaves untouched (H3) is still part of the step's outcome
-        uint32_t stale_merged[4] = {0, 0, 0, 0};
-        float stale_reward = 0.0f;
-        int32_t id_before = 0;
-        if (a.out.merged) {
-            const uint4 m = reinterpret_cast<const uint4 *>(st.merged)[i];
-            stale_merged[0] = m.x; stale_merged[1] = m.y; stale_merged[2] = m.z; stale_merged[3] = m.w;
-        }
-        if (a.out.reward) stale_reward = st.reward[i];
-        if (a.out.id) id_before = st.id[i];
+        const int64_t i = live ? i0 : M - 1;
+        Inputs nxt = in;
+        if (!SINGLE && r + 1 < R && wbase + (int64_t)(r + 1) * 64 < M) load_inputs(r + 1, nxt);
+        s.board = in.board;
+        s.valid = in.valid;
+        s.step = in.step;
+        s.score = in.score;
+        const uint32_t t_before = in.t_before, action = in.action;
+        const uint32_t perm[4] = {in.perm[0], in.perm[1], in.perm[2], in.perm[3]};
+        const uint32_t stale_merged[4] = {in.stale_merged[0], in.stale_merged[1], in.stale_merged[2], in.stale_merged[3]};
+        const float stale_reward = in.stale_reward;
+        const int32_t id_before = in.id_before;
+        in = nxt;
 
         uint32_t invalid = 1;
         term = t_before;
@@ -202,9 +239,6 @@ __global__ __launch_bounds__(kBlk) void k_step_prepare(const ml2048_step_prepare
         if (a.hist_counts && redeal) { // RunnerStats._update_count, runner.py:120-136
             const uint32_t mx = max_cell(s.board);
             if (mx < 20) atomicAdd(&hist[mx], 1);
-        }
-        if (!SINGLE && live && term != 0 && !invalid) {
-            // nothing: st.terminated already holds 1; phase 2 re-reads it
         }
     }
     if (lane == 0) wave_cnt[wave] = my_cnt;

@@ -107,8 +107,33 @@ def test_step_prepare_vs_oracle_single_pass(amd, oracle, torch_cuda, M, N, rewar
     (600000, 40, "normal", True),     # 3 iterations per wave, ragged
     (2097152, 24, "rank", False),     # C4's total size
 ])
-def test_step_prepare_vs_oracle_multi_pass(amd, oracle, torch_cuda, M, N, reward, masked):
+def test_step_prepare_vs_oracle_large(amd, oracle, torch_cuda, M, N, reward, masked):
     _drive(amd, oracle, torch_cuda, M, N, reward, masked=masked, full_every=13)
+
+
+@pytest.mark.parametrize("M,blocks,N,reward,masked", [
+    (5000, 7, 60, "improved", True),      # 3 x 64 boards per wave, ragged
+    (262144, 100, 30, "normal", False),   # 11 iterations per wave
+    (70001, 64, 40, "maxcell", True),
+])
+def test_step_prepare_vs_oracle_multi_pass(amd, oracle, torch_cuda, monkeypatch, M, blocks, N, reward, masked):
+    """The multi-pass form (more than 262 144 boards: a wave walks its boards 64 at a time, phase 2 re-reads what
+    phase 1 wrote) with many iterations per wave, forced at test sizes through ML2048_SP_MAX_BLOCKS."""
+    monkeypatch.setenv("ML2048_SP_MAX_BLOCKS", str(blocks))
+    _drive(amd, oracle, torch_cuda, M, N, reward, masked=masked, full_every=7)
+    # observations of the multi-pass form
+    import torch.nn.functional as F
+    torch = torch_cuda
+    env = amd.VecGame(M)
+    env.reset(3)
+    env.prepare()
+    pol = amd.RandomPolicy(seed=2, masked=True)
+    obs = torch.empty((M, 16, 4, 4), dtype=torch.float32, device="cuda")
+    a, _ = pol.sample_actions_u8(env.valid_actions)
+    for t in range(70):
+        a = env.step_prepare_torch(a, onehot=obs, sample=pol)["actions"]
+    x = F.one_hot(env.board.cpu().long(), 16).float()
+    assert torch.equal(obs.cpu(), torch.reshape(torch.permute(x, (0, 2, 1)), (-1, 16, 4, 4)))
 
 
 @pytest.mark.parametrize("M", [4096, 300000])
