@@ -43,6 +43,18 @@ __device__ __forceinline__ float byte_f32(uint32_t x, int j) { return (float)((x
 
 __device__ __forceinline__ float lrelu(float x, float slope) { return fmaxf(x, x * slope); } // 0 <= slope <= 1
 
+// the 9 KiB of activations per board are written once and read once, by the GEMM behind this kernel: non-temporal
+// stores (ML2048_ENC_NT=0: A/B)
+__device__ __forceinline__ void store_act(float4 *dst, float a, float b, float c, float d) {
+#if !defined(ML2048_ENC_NT) || ML2048_ENC_NT
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f q = {a, b, c, d};
+    __builtin_nontemporal_store(q, reinterpret_cast<v4f *>(dst));
+#else
+    *dst = make_float4(a, b, c, d);
+#endif
+}
+
 __global__ __launch_bounds__(kThreads) void k_encoder_front(const uint4 *__restrict__ board, int64_t N,
                                                             const float *__restrict__ w_full, const float *__restrict__ b_full,
                                                             const float *__restrict__ w_rows, const float *__restrict__ b_rows,
@@ -89,7 +101,7 @@ __global__ __launch_bounds__(kThreads) void k_encoder_front(const uint4 *__restr
                     acc.w = __builtin_fmaf(f, v.w, acc.w);
                 }
             }
-            out_full[n * 64 + lane] = make_float4(lrelu(acc.x, slope), lrelu(acc.y, slope), lrelu(acc.z, slope), lrelu(acc.w, slope));
+            store_act(out_full + n * 64 + lane, lrelu(acc.x, slope), lrelu(acc.y, slope), lrelu(acc.z, slope), lrelu(acc.w, slope));
         }
         // ---- rows and columns: unit = one channel c (class k = c >> 4), its four positions
 #pragma unroll
@@ -119,8 +131,8 @@ __global__ __launch_bounds__(kThreads) void k_encoder_front(const uint4 *__restr
                 rows[q] = a;
                 cols[q] = d;
             }
-            out_rows[n * kCh + c] = make_float4(lrelu(rows[0], slope), lrelu(rows[1], slope), lrelu(rows[2], slope), lrelu(rows[3], slope));
-            out_cols[n * kCh + c] = make_float4(lrelu(cols[0], slope), lrelu(cols[1], slope), lrelu(cols[2], slope), lrelu(cols[3], slope));
+            store_act(out_rows + n * kCh + c, lrelu(rows[0], slope), lrelu(rows[1], slope), lrelu(rows[2], slope), lrelu(rows[3], slope));
+            store_act(out_cols + n * kCh + c, lrelu(cols[0], slope), lrelu(cols[1], slope), lrelu(cols[2], slope), lrelu(cols[3], slope));
         }
     }
 }

@@ -92,7 +92,14 @@ __device__ __forceinline__ void emit_obs(const Board &b, int64_t base, int cnt, 
             o.y = (eq & 0x00008000u) ? 1.0f : 0.0f;
             o.z = (eq & 0x00800000u) ? 1.0f : 0.0f;
             o.w = (eq & 0x80000000u) ? 1.0f : 0.0f;
+#if defined(ML2048_OBS_NT) && ML2048_OBS_NT // A/B only: non-temporal observation stores LOSE here (C3: 56 vs 44 us per
+            // env step) - the 256 MiB observation is rewritten every step and lives in the Infinity Cache
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f q = {o.x, o.y, o.z, o.w};
+            __builtin_nontemporal_store(q, reinterpret_cast<v4f *>(onehot) + (base + j) * 64 + lane);
+#else
             reinterpret_cast<float4 *>(onehot)[(base + j) * 64 + lane] = o;
+#endif
         }
     }
     if (board_i64) {

@@ -73,6 +73,28 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ml2048_timer_arm(None) == -1 and lib.ml2048_timer_elapsed_ms(None, None) == -1
     lib.ml2048_timer_destroy(None)
     assert lib.ml2048_sched_stream_take(None, None, 0, None, None, None, None, None, None, None, None) == -1
+    # the one-launch step: one argument struct, checked field by field before any launch
+    assert lib.ml2048_step_prepare(None, None) == -1
+    A = _lib.StepPrepareArgs()
+    A.M, A.st = 64, ok
+    assert lib.ml2048_step_prepare(None, C.byref(A)) == -1 and b"actions" in lib.ml2048_last_error()
+    A.actions, A.action_dtype, A.reward_kind = 4096, 0, 7
+    assert lib.ml2048_step_prepare(None, C.byref(A)) == -1 and b"reward_kind" in lib.ml2048_last_error()
+    A.reward_kind, A.randperm_step = 1, 4096
+    assert lib.ml2048_step_prepare(None, C.byref(A)) == -1 and b"randperm_prepare" in lib.ml2048_last_error()
+    A.randperm_prepare, A.two_mask_step = 4096, 1 << 16
+    assert lib.ml2048_step_prepare(None, C.byref(A)) == -1 and b"two_mask" in lib.ml2048_last_error()
+    A.two_mask_step = 0xFFFF
+    assert lib.ml2048_step_prepare(None, C.byref(A)) == -1 and b"scratch" in lib.ml2048_last_error()
+    A.game_count = A.n_reset = 4096
+    A.scratch = 4100
+    assert lib.ml2048_step_prepare(None, C.byref(A)) == -2                # scratch alignment
+    A.scratch = 4096
+    A.onehot = 4104
+    assert lib.ml2048_step_prepare(None, C.byref(A)) == -2                # onehot alignment
+    A.onehot, A.next_logp = None, 4096
+    assert lib.ml2048_step_prepare(None, C.byref(A)) == -1 and b"next_logp" in lib.ml2048_last_error()
+    assert lib.ml2048_step_prepare_scratch_bytes() >= 1024 * 8 + 4
 
 
 def test_python_api_fails_loudly_without_gpu():
