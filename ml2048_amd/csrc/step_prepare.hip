@@ -21,6 +21,10 @@
 // sampling), and only then sums the words of the workgroups below it (<= 1023 words, 4 per thread, one L2 round
 // trip: no serial look-back chain).  With <= 1024 workgroups of 256 threads all of them are resident at once and
 // workgroups are dispatched in index order, so waiting for lower indices cannot deadlock.
+// (Measured and dropped: the observation of the boards that are not re-dealt written already in the step phase, so
+// that its stores would drain under the barrier and the count exchange: C3 44.5 -> 54.3 us per env step - the barrier's
+// s_waitcnt then waits for 64 KiB of stores per wave BEFORE the counts are published, and on gfx9 the probes' loads
+// retire behind those stores either way.)
 // (Measured and dropped: up to 65 536 workgroups - one pass for any M up to 16.7 M boards - with a two-level exchange,
 // own group of 64 + totals of the lower groups: the words read grow with workgroups^2 / 128 and every one is a
 // device-scope access; 4 M boards 180 vs 129 us per launch, 16.7 M 753 vs 490-690 us, and the second barrier costs

@@ -371,7 +371,7 @@ class VecGame:
             c = _lib.Pcg64State(s >> 64, s & m64, inc >> 64, inc & m64, int(st["has_uint32"]), int(st["uinteger"]))
             self._sstream = L.ml2048_sched_stream_create(C.byref(c), self._rng.randperm.ctypes.data,
                                                          self._rng.randfloat.ctypes.data, self._rng.rand_step, N,
-                                                         self._two_prob, 3)
+                                                         self._two_prob, int(os.environ.get("ML2048_STREAM_DEPTH", "6")))
             if not self._sstream:
                 raise _lib.Ml2048Error("ml2048_sched_stream_create failed")
             self._sstream_n = N

@@ -35,13 +35,13 @@ def _same_state(env, ref, what):
     assert np.array_equal(env._prev_valid_actions, ref._prev_valid_actions), what
 
 
-def _pair(amd, oracle, M, reward, spawn, seed):
+def _pair(amd, oracle, M, reward, spawn, seed, two_prob=0.8):
     if spawn == "rocrand":
-        env = amd.VecGame(M, reward, spawn="rocrand", spawn_seed=0xFACE)
-        ref = oracle.OracleVecGame(M, reward, fast_seed=0xFACE)
+        env = amd.VecGame(M, reward, spawn="rocrand", spawn_seed=0xFACE, two_prob=two_prob)
+        ref = oracle.OracleVecGame(M, reward, fast_seed=0xFACE, two_prob=two_prob)
     else:
-        env = amd.VecGame(M, reward)
-        ref = oracle.OracleVecGame(M, reward)
+        env = amd.VecGame(M, reward, two_prob=two_prob)
+        ref = oracle.OracleVecGame(M, reward, two_prob=two_prob)
     env.reset(seed)
     ref.reset(seed)
     (i1,) = env.prepare()
@@ -50,9 +50,10 @@ def _pair(amd, oracle, M, reward, spawn, seed):
     return env, ref
 
 
-def _drive(amd, oracle, torch, M, N, reward, *, masked, spawn="table", seed=20241008, full_every=8, with_out=True):
+def _drive(amd, oracle, torch, M, N, reward, *, masked, spawn="table", seed=20241008, full_every=8, with_out=True,
+           two_prob=0.8):
     """N fused env steps; the fused sampler provides the actions from step 1 on."""
-    env, ref = _pair(amd, oracle, M, reward, spawn, seed)
+    env, ref = _pair(amd, oracle, M, reward, spawn, seed, two_prob)
     pol = amd.RandomPolicy(seed=11, masked=masked)
     out = env.new_step_out() if with_out else None
     hist = torch.zeros(20, dtype=torch.int32, device="cuda")
@@ -139,6 +140,13 @@ def test_step_prepare_vs_oracle_multi_pass(amd, oracle, torch_cuda, monkeypatch,
 @pytest.mark.parametrize("M", [4096, 300000])
 def test_step_prepare_rocrand_spawn(amd, oracle, torch_cuda, M):
     _drive(amd, oracle, torch_cuda, M, 70, "improved", masked=True, spawn="rocrand", seed=5)
+
+
+@pytest.mark.parametrize("spawn,two_prob", [("table", 0.37), ("table", 1.0), ("rocrand", 0.37), ("table", 0.0)])
+def test_step_prepare_other_two_prob(amd, oracle, torch_cuda, spawn, two_prob):
+    """H2: the 2/4 decision is `float64(randfloat[cell]) < two_prob`; the fused kernel takes it as a host-computed
+    mask (table mode) or a 32-bit threshold (rocRAND mode)."""
+    _drive(amd, oracle, torch_cuda, 3000, 90, "normal", masked=True, spawn=spawn, seed=8, two_prob=two_prob)
 
 
 def test_step_prepare_without_optional_outputs_and_mixed_with_the_other_apis(amd, oracle, torch_cuda):
