@@ -254,7 +254,7 @@ int ml2048_devrng_schedule(void *stream, const void *workspace, ml2048_devrng *r
  * expanded_tables != 0: perm_epochs is uint8[max_epochs][1024][32] - each row followed by its inverse
  * permutation in board layout, the table form ml2048_rollout_chain consumes.
  * On a non-NULL stream the dozen dependent launches of one call are captured once per argument set into a
- * hipGraph (the library keeps the last 8) and replayed with one hipGraphLaunch; calls with repeating
+ * hipGraph (the library keeps the last 96) and replayed with one hipGraphLaunch; calls with repeating
  * arguments (a ring of output buffers) therefore cost one enqueue.  ML2048_DEVRNG_GRAPH=0 in the environment
  * keeps the direct launches.  The workspace must stay allocated while such calls may repeat.
  */
@@ -437,7 +437,8 @@ typedef struct ml2048_step_out {
  *   game_count, n_reset, reset_indices (may be NULL)                  as ml2048_prepare
  *   scratch            ml2048_step_prepare_scratch_bytes() bytes of device memory, 8-byte aligned, ZEROED ONCE by the
  *                      caller and then owned by this env (epoch-tagged status words + the epoch itself, advanced on
- *                      the device: the launch may be captured in a hipGraph and replayed)
+ *                      the device, so no host-side launch counter is baked into the arguments; a hipGraph of several steps would still
+ *                      need the per-step row bases in device memory - they are plain arguments here)
  *   onehot             optional float32[M][16][4][4] observation of the post-prepare boards (_network.py:91-95,105)
  *   board_i64          optional int64[M][16] of the same boards (_network.py:87-88)
  *   next_actions       optional uint8[M]: RandomPolicy's draw for step t+1 on the post-prepare masks

@@ -30,7 +30,7 @@
 // device-scope access; 4 M boards 180 vs 129 us per launch, 16.7 M 753 vs 490-690 us, and the second barrier costs
 // C3 47.9 vs 44.9 us.)
 // The epoch lives in device memory next to the status words (the last workgroup advances it once all others have
-// published, i.e. have read it), so the launch can be captured in a hipGraph and replayed.
+// published, i.e. have read it): no host-side launch counter is baked into the arguments.
 //
 // HBM traffic per board: the per-step kernel's 99 B (R board 16 + valid 4 + step 4 + score 4 + action 1; W prev
 // 16 + 4; on a valid move W board 16 + merged 16 + valid 4 + step 4 + score 4 + reward 4 + flags 2) + 1 B
