@@ -608,6 +608,47 @@ ML_HD bool step_pre_lazy(StepRegs &s, uint32_t action, int reward_kind, uint32_t
     return true;
 }
 
+// ---- the score as a function of the board ------------------------------------------------------------------------
+// `score` accumulates reward_fn_normal = the value of every tile a merge creates (game_numba.py:408-438, :729-731).
+// A tile 2^e that was built from 2-tiles alone has collected (e-1)*2^e on the way; every 4 that was spawned instead of
+// being merged from two 2s saves one reward of 4.  The 4s follow from the board too: T tiles were spawned since the deal
+// (2 + one per valid move = 2 + step), worth sum(2^e) = 2*(T - B) + 4*B together, B of them 4s.  Hence, exactly,
+//     score = sum over tiles of (e-3)*2^e  +  8  +  4*step                       (verified move by move against the
+// reference-derived oracle on 49 000 games, tests/test_host_ops.py::test_score_is_a_function_of_board_and_step)
+// and a rollout that only has to deliver the score AFTER its last step needs no reward arithmetic inside its loop:
+// score_end = score_start - potential(start) + potential(end), restarting from 0 at a re-deal.  Integers below 2^24
+// throughout (phi_guard), so the float32 running sum the reference keeps (H8) holds the same exact integers.
+ML_HD int32_t score_potential(const Board &b, int32_t step) {
+    int32_t sum = 8 + 4 * step;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int32_t e = (int32_t)((b.r[q] >> (8 * j)) & 0xFFu);
+            sum += e ? (e - 3) * (int32_t)(1u << (e & 31)) : 0;
+        }
+    }
+    return sum;
+}
+// tiles <= 2^15, an integer score in [0, 2^21): with at most 65 536 steps the tile sum stays below 2^20 and the score
+// below 2^21 + 17 * 786 432 < 2^24
+ML_HD bool phi_guard(const Board &b, float score) {
+    const bool small = ((b.r[0] | b.r[1] | b.r[2] | b.r[3]) & 0xF0F0F0F0u) == 0u;
+    return small && score >= 0.0f && score < 2097152.0f && (float)(int32_t)score == score;
+}
+// step_pre_lazy without any reward arithmetic (reward_fn_normal only): the caller restores score and reward after
+// its last step from score_potential() and the carried merge exponents
+ML_HD bool step_pre_lazy_phi(StepRegs &s, uint32_t action, uint32_t &mexp_first, uint32_t &mexp_second) {
+    const Board prev = s.board;
+    const MoveResult mv = move_board(prev, action & 3u);
+    if (action >= 4u || !board_differs(mv.board, prev)) return false;
+    mexp_first = mv.mexp_first;
+    mexp_second = mv.mexp_second;
+    s.board = mv.board;
+    s.step += 1;
+    return true;
+}
+
 ML_HD void step_post_lazy(StepRegs &s) { s.terminated = no_move_left(s.board); }
 
 // the same when the spawn reported which cells were empty before it (spawn_table_inv): the board is full now exactly

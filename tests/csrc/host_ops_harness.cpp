@@ -121,6 +121,17 @@ void h_merged_value_sum(const uint32_t *words, int64_t n, uint32_t *out) {
     for (int64_t i = 0; i < n; ++i) out[i] = ml2048::merged_value_sum(words[2 * i], words[2 * i + 1]);
 }
 
+// score_potential / phi_guard on n boards (16 bytes each)
+void h_score_potential(const uint8_t *boards, const int32_t *step, const float *score, int64_t n, int32_t *pot,
+                       uint8_t *guard) {
+    for (int64_t i = 0; i < n; ++i) {
+        ml2048::Board b;
+        memcpy(b.r, boards + 16 * i, 16);
+        pot[i] = ml2048::score_potential(b, step[i]);
+        guard[i] = ml2048::phi_guard(b, score[i]) ? 1 : 0;
+    }
+}
+
 void h_transpose(const uint8_t *in, uint8_t *out) {
     Board b;
     memcpy(b.r, in, 16);

@@ -146,3 +146,39 @@ def test_plain_masked(amd, oracle, M, lengths, reward):
 ])
 def test_plain_rocrand_spawn(amd, oracle, M, lengths, masked):
     _run(amd, oracle, M, lengths, "improved", None, 11, masked=masked, spawn="rocrand")
+
+
+# ---- the lazy loop's score comes from the board (board_ops.hpp score_potential); states outside its guard -----------
+def test_plain_rollout_on_states_outside_the_score_guard(amd, oracle):
+    """Fractional / huge / negative scores and tiles above 2^15 loaded into the env: those waves take the eager loop
+    (per-step float32 accumulation exactly as the reference); the others the lazy one.  All equal the oracle."""
+    M, N = 4096, 150
+    env = amd.VecGame(M, "normal", schedule="host-async")
+    ref = oracle.OracleVecGame(M, "normal")
+    env.reset(11)
+    ref.reset(11)
+    arng = np.random.default_rng(1)
+    for _ in range(30):   # some play first, in lock-step: boards, scores, steps of games in progress
+        env.prepare()
+        ref.prepare()
+        a = arng.integers(0, 4, size=M)
+        env.step(a)
+        ref.step(a)
+    env.prepare()
+    ref.prepare()
+    d = ref._data
+    d["score"][0:64] += 0.5                    # one whole wave fractional
+    d["score"][64] = 4194304.0                 # one lane of the next wave beyond the guard's range
+    d["score"][200] = 16777215.0               # float32 adds stop being exact during the rollout
+    d["score"][300] = -8.0
+    d["board"][400, 5] = 16                    # a 65 536 tile
+    d["valid_actions"][400] = oracle.compute_valid_actions(d["board"][400])[0]
+    env.load_records(d)
+    # the rollout's first prepare() is the oracle's next prepare(): nothing is terminated after the one above
+    env.rollout(N, masked=False, act_seed=ACT_SEED, act_counter=5)
+    for t in range(N):
+        ref.prepare()
+        a, _ = oracle.sample_actions(ref._data["valid_actions"], ACT_SEED, 5 + t, masked=False)
+        ref.step(a)
+    _assert_same(env, ref, "states outside the score guard")
+    assert env._game_count == ref._game_count

@@ -124,6 +124,48 @@ def test_merged_value_sum_all_byte_values(H):
     assert np.array_equal(out.astype(np.int64), want)
 
 
+def test_score_is_a_function_of_board_and_step(H, oracle):
+    """board_ops.hpp score_potential: in every game played from a deal, after every prepare() and every step(),
+    score == sum over tiles of (e-3)*2^e + 8 + 4*step - what lets the fused rollout's lazy loop drop the reward
+    arithmetic (reward_fn_normal accumulates into score whatever reward_fn is, game_numba.py:729-731).  Checked move
+    by move on the reference-derived oracle, with invalid moves (H3) and both 2/4 probabilities; and the guard that
+    keeps every intermediate sum an exact float32 integer."""
+    H.h_score_potential.argtypes = [C.c_void_p] * 3 + [C.c_int64] + [C.c_void_p] * 2
+    H.h_score_potential.restype = None
+    games = 0
+    for two_prob, kind in ((0.8, "improved"), (0.3, "normal")):
+        M = 2048
+        env = oracle.OracleVecGame(M, kind, two_prob=two_prob)
+        env.reset(5)
+        rng = np.random.default_rng(0)
+        pot = np.zeros(M, np.int32)
+        guard = np.zeros(M, np.uint8)
+        for t in range(500):
+            for phase in range(2):
+                if phase == 0:
+                    env.prepare()
+                else:
+                    env.step(rng.integers(0, 4, size=M))
+                d = env._data
+                board = np.ascontiguousarray(d["board"])
+                step = np.ascontiguousarray(d["step"])
+                score = np.ascontiguousarray(d["score"])
+                H.h_score_potential(_p(board), _p(step), _p(score), M, _p(pot), _p(guard))
+                assert np.array_equal(pot.astype(np.float32), score), (two_prob, t, phase)
+                assert guard.all()
+        games += env._game_count
+    assert games > 20000
+    # the guard: tiles above 2^15, negative / fractional / large scores are sent to the eager loop
+    boards = np.zeros((5, 16), np.uint8)
+    boards[0, 3] = 16
+    scores = np.array([0.0, -1.0, 0.5, 2097152.0, 2097151.0], np.float32)
+    steps = np.zeros(5, np.int32)
+    pot = np.zeros(5, np.int32)
+    guard = np.zeros(5, np.uint8)
+    H.h_score_potential(_p(boards), _p(steps), _p(scores), 5, _p(pot), _p(guard))
+    assert guard.tolist() == [0, 0, 0, 0, 1]
+
+
 def test_valid_empties_maxcell_vs_oracle(H, oracle):
     rng = np.random.default_rng(6)
     n = 20000
