@@ -636,14 +636,15 @@ ML_HD bool phi_guard(const Board &b, float score) {
     const bool small = ((b.r[0] | b.r[1] | b.r[2] | b.r[3]) & 0xF0F0F0F0u) == 0u;
     return small && score >= 0.0f && score < 2097152.0f && (float)(int32_t)score == score;
 }
-// step_pre_lazy without any reward arithmetic (reward_fn_normal only): the caller restores score and reward after
-// its last step from score_potential() and the carried merge exponents
-ML_HD bool step_pre_lazy_phi(StepRegs &s, uint32_t action, uint32_t &mexp_first, uint32_t &mexp_second) {
+// step_pre_lazy without any reward arithmetic: the caller keeps the board and the action of the last VALID move
+// (`pv`, `pv_action`) and restores score (score_potential), reward and merged[] (one more move_board on `pv`) after its
+// last step - the record only ever shows the last valid move's reward and buckets (H3)
+ML_HD bool step_pre_lazy_pv(StepRegs &s, uint32_t action, Board &pv, uint32_t &pv_action) {
     const Board prev = s.board;
     const MoveResult mv = move_board(prev, action & 3u);
     if (action >= 4u || !board_differs(mv.board, prev)) return false;
-    mexp_first = mv.mexp_first;
-    mexp_second = mv.mexp_second;
+    pv = prev;
+    pv_action = action;
     s.board = mv.board;
     s.step += 1;
     return true;

@@ -901,14 +901,18 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
     // step.  ~70 fewer VALU operations per board-step; identical results (tests/test_host_ops.py,
     // tests/test_gpu_parity.py).  The optional outputs need the mask every step: always eager.
     bool lazy = !EXTRAS && !masked && __all(valid_consistent(s.board, s.valid) ? 1 : 0);
-    // reward_fn_normal: the lazy loop carries no reward arithmetic at all - the score after the last step follows from
-    // the board and the step counter (board_ops.hpp score_potential; ~28 VALU per board-step), the reward field from
-    // the carried merge exponents of the last valid move.  A wave with a board or a score outside the guard's range
-    // (never in play from a deal) takes the eager loop.
-    constexpr bool kPhi = !EXTRAS && KIND == REWARD_NORMAL;
+    // The lazy loop carries no reward arithmetic at all: the score after the last step follows from the board and the
+    // step counter (board_ops.hpp score_potential; `score` accumulates reward_fn_normal whatever reward_fn is, :729-731),
+    // and the record's reward / merged[] are the LAST valid move's (H3), recomputed once from that move's board and
+    // action (`pv`, `pv_action`), which is all the loop keeps.  ~17 VALU per board-step for reward_fn_normal, the whole
+    // reward function for the others.  A wave with a board or a score outside the guard's range (never in play from a
+    // deal) takes the eager loop.
+    constexpr bool kPhi = !EXTRAS;
     if (kPhi) lazy = lazy && N <= 65536 && __all(phi_guard(s.board, s.score) ? 1 : 0);
     int32_t phi_acc = 0; // score - potential, as of the game's start inside this rollout
     if (kPhi && lazy) phi_acc = (int32_t)s.score - score_potential(s.board, s.step);
+    Board pv = s.board;      // the board the last valid move started from ...
+    uint32_t pv_action = 4u; // ... and its action (4 = none since the deal / since the rollout began)
     auto run_steps = [&](auto lazy_tag) {
         constexpr bool LAZY = decltype(lazy_tag)::value;
         for (int t0 = 0; t0 < N; t0 += kFlagChunk) {
@@ -999,7 +1003,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                         deal_table(s.board, head, two_mask);
                     }
                     if (!LAZY) s.valid = valid_actions(s.board);
-                    if (LAZY && kPhi) phi_acc = 0; // score 0 on the dealt board at step 0: its potential is 0
+                    if (LAZY && kPhi) { // score 0 on the dealt board at step 0: its potential is 0
+                        phi_acc = 0;
+                        pv_action = 4u;
+                    }
                     last = t;
                 }
                 // ---- sample (policy/random.py:17-27)
@@ -1024,8 +1031,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                 // ---- step (game_numba.py:660-738)
                 prev_board = s.board;
                 if (!LAZY) prev_valid = s.valid;
-                if (LAZY ? (kPhi ? step_pre_lazy_phi(s, action, mexp_first, mexp_second)
-                                 : step_pre_lazy(s, action, KIND, mexp_first, mexp_second))
+                if (LAZY ? step_pre_lazy_pv(s, action, pv, pv_action)
                          : step_pre_lite(s, action, KIND, mexp_first, mexp_second)) {
                     merged_stale = true;
                     uint32_t empties = 0;
@@ -1129,10 +1135,17 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
             run_steps(std::true_type{});
             s.valid = valid_actions(s.board);
             prev_valid = valid_actions(prev_board);
-            if (kPhi) {
-                s.score = (float)(phi_acc + score_potential(s.board, s.step));
-                // the record's reward is the last valid move's (H3); after a re-deal with no valid move since: 0
-                if (merged_stale) s.reward = (float)merged_value_sum(mexp_first, mexp_second);
+            s.score = (float)(phi_acc + score_potential(s.board, s.step));
+            if (merged_stale) { // a deal or a valid move happened: the record shows the last valid move since the deal
+                s.reward = 0.0f;
+                s.merged[0] = s.merged[1] = s.merged[2] = s.merged[3] = 0;
+                if (pv_action < 4u) {
+                    const MoveResult mv = move_board(pv, pv_action);
+                    const MergeStats ms = merge_stats(mv.mexp_first, mv.mexp_second);
+                    s.merged[0] = ms.merged[0]; s.merged[1] = ms.merged[1]; s.merged[2] = ms.merged[2]; s.merged[3] = ms.merged[3];
+                    s.reward = (float)reward_value(KIND, mv.board, pv, ms);
+                }
+                merged_stale = false;
             }
         }
     }
