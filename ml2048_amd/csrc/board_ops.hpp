@@ -558,6 +558,18 @@ ML_HD bool step_pre_lite(StepRegs &s, uint32_t action, int reward_kind, uint32_t
     return true;
 }
 
+// step_pre_lite without any reward arithmetic (see step_pre_lazy_pv below): validity from the maintained mask, the
+// caller keeps the board and the action of the last valid move
+ML_HD bool step_pre_lite_pv(StepRegs &s, uint32_t action, Board &pv, uint32_t &pv_action) {
+    const bool ok = action < 4u && ((s.valid >> (8u * (action & 3u))) & 0xFFu) != 0u;
+    if (!ok) return false;
+    pv = s.board;
+    pv_action = action;
+    s.board = move_board(pv, action).board;
+    s.step += 1;
+    return true;
+}
+
 // ---- the same step without a maintained valid-action mask ---------------------------------------
 // For uniform (unmasked) sampling nothing reads the mask between steps: an action is valid exactly
 // when the move changes the board, and `terminated` (= no valid action, :735-736) only needs "board

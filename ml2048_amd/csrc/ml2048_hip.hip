@@ -907,14 +907,16 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
     // action (`pv`, `pv_action`), which is all the loop keeps.  ~17 VALU per board-step for reward_fn_normal, the whole
     // reward function for the others.  A wave with a board or a score outside the guard's range (never in play from a
     // deal) takes the eager loop.
-    constexpr bool kPhi = !EXTRAS;
-    if (kPhi) lazy = lazy && N <= 65536 && __all(phi_guard(s.board, s.score) ? 1 : 0);
+    // The same holds with a maintained mask (masked sampling without optional outputs): `defer`.
+    const bool defer = !EXTRAS && N <= 65536 && __all(phi_guard(s.board, s.score) ? 1 : 0);
+    lazy = lazy && defer;
     int32_t phi_acc = 0; // score - potential, as of the game's start inside this rollout
-    if (kPhi && lazy) phi_acc = (int32_t)s.score - score_potential(s.board, s.step);
+    if (defer) phi_acc = (int32_t)s.score - score_potential(s.board, s.step);
     Board pv = s.board;      // the board the last valid move started from ...
     uint32_t pv_action = 4u; // ... and its action (4 = none since the deal / since the rollout began)
-    auto run_steps = [&](auto lazy_tag) {
+    auto run_steps = [&](auto lazy_tag, auto defer_tag) {
         constexpr bool LAZY = decltype(lazy_tag)::value;
+        constexpr bool DEFER = decltype(defer_tag)::value; // no reward arithmetic in the loop (always with LAZY)
         for (int t0 = 0; t0 < N; t0 += kFlagChunk) {
             const int t1 = t0 + kFlagChunk < N ? t0 + kFlagChunk : N;
 #ifdef ML2048_LONE_WAVE
@@ -1003,7 +1005,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                         deal_table(s.board, head, two_mask);
                     }
                     if (!LAZY) s.valid = valid_actions(s.board);
-                    if (LAZY && kPhi) { // score 0 on the dealt board at step 0: its potential is 0
+                    if (DEFER) { // score 0 on the dealt board at step 0: its potential is 0
                         phi_acc = 0;
                         pv_action = 4u;
                     }
@@ -1031,8 +1033,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                 // ---- step (game_numba.py:660-738)
                 prev_board = s.board;
                 if (!LAZY) prev_valid = s.valid;
-                if (LAZY ? step_pre_lazy_pv(s, action, pv, pv_action)
-                         : step_pre_lite(s, action, KIND, mexp_first, mexp_second)) {
+                if (LAZY    ? step_pre_lazy_pv(s, action, pv, pv_action)
+                    : DEFER ? step_pre_lite_pv(s, action, pv, pv_action)
+                            : step_pre_lite(s, action, KIND, mexp_first, mexp_second)) {
                     merged_stale = true;
                     uint32_t empties = 0;
                     if (FAST) {
@@ -1127,14 +1130,18 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
         }
     };
     if constexpr (EXTRAS) {
-        run_steps(std::false_type{});
+        run_steps(std::false_type{}, std::false_type{});
     } else {
-        if (!lazy) {
-            run_steps(std::false_type{});
+        if (!defer) {
+            run_steps(std::false_type{}, std::false_type{});
         } else {
-            run_steps(std::true_type{});
-            s.valid = valid_actions(s.board);
-            prev_valid = valid_actions(prev_board);
+            if (lazy) {
+                run_steps(std::true_type{}, std::true_type{});
+                s.valid = valid_actions(s.board);
+                prev_valid = valid_actions(prev_board);
+            } else {
+                run_steps(std::false_type{}, std::true_type{});
+            }
             s.score = (float)(phi_acc + score_potential(s.board, s.step));
             if (merged_stale) { // a deal or a valid move happened: the record shows the last valid move since the deal
                 s.reward = 0.0f;
