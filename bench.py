@@ -61,6 +61,9 @@ def parse():
                          "(C3 pipeline); stepwise3: the reference-shaped per-step API (prepare, sample, step launches)")
     ap.add_argument("--masked", type=int, default=None, help="masked-uniform actions (default: unmasked, C2; obs: masked)")
     ap.add_argument("--seed", type=int, default=20241008)
+    ap.add_argument("--spawn", choices=["table", "rocrand"], default="table",
+                    help="table (default): the reference's PCG64 tables, bit-exact with numba; rocrand: the rocRAND Philox "
+                         "spawn (same game statistically, no host schedule)")
     ap.add_argument("--step-mapping", choices=["lane", "wave"], default="lane",
                     help="stepwise3: lane-per-board step kernel (default) or one wavefront per board")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -180,7 +183,7 @@ def _traffic(key: str):
     return None, None
 
 
-def rollout_roofline(M: int, N: int, avg_ms: float, masked: bool, traj: bool):
+def rollout_roofline(M: int, N: int, avg_ms: float, masked: bool, traj: bool, spawn: str = "table"):
     """VALU-issue roofline of k_rollout (fused) / HBM-write roofline of the trajectory-writing instantiation."""
     waves = (M + 63) // 64
     if traj:
@@ -191,7 +194,7 @@ def rollout_roofline(M: int, N: int, avg_ms: float, masked: bool, traj: bool):
                 "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tb, "traffic_source": src,
                 "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg,
                 "note": "algorithmic = the 54 B/board-step of REPLAY_SPEC transitions this launch writes"}
-    variant = "masked" if masked else "plain"
+    variant = ("masked" if masked else "plain") + ("" if spawn == "table" else "-rocrand")
     pass_ = "small" if M <= 131072 else "large"
     ent = _inst_table().get(f"k_rollout:{variant}:{pass_}")
     tb, src = _traffic(f"k_rollout:M={M}:N={N}")
@@ -316,8 +319,8 @@ def main():
         return max_over_ranks(time.perf_counter() - t0, dist)
 
     # ---- workloads ----------------------------------------------------------------------------------------------
-    def make_fused(m, n, masked_, mode, schedule, seed_off=0):
-        env = amd.VecGame(m, amd.reward_fn_normal, device=dev, schedule=schedule)
+    def make_fused(m, n, masked_, mode, schedule, seed_off=0, spawn="table"):
+        env = amd.VecGame(m, amd.reward_fn_normal, device=dev, schedule=schedule, spawn=spawn, spawn_seed=args.seed)
         env.reset(args.seed + rank + seed_off)
         traj = None
         if mode == "fused-traj":  # every step's transition materialised: 54 B written per board-step
@@ -375,7 +378,7 @@ def main():
         return step, [], env
 
     if args.mode in ("fused", "fused-traj"):
-        step_fn, timers, env = make_fused(M, N, masked, args.mode, args.schedule)
+        step_fn, timers, env = make_fused(M, N, masked, args.mode, args.schedule, spawn=args.spawn)
     elif args.mode in ("stepwise", "obs"):
         step_fn, timers, env = make_stepwise(M, N, masked, args.mode == "obs")
     else:
@@ -385,7 +388,7 @@ def main():
     avg_ms = timers_avg_ms(timers)
 
     if args.mode in ("fused", "fused-traj"):
-        roofline = rollout_roofline(M, N, avg_ms, masked, args.mode == "fused-traj")
+        roofline = rollout_roofline(M, N, avg_ms, masked, args.mode == "fused-traj", args.spawn)
     elif args.mode in ("stepwise", "obs"):
         roofline = step_prepare_roofline(M, avg_ms, args.mode == "obs", True)
     else:
@@ -424,20 +427,17 @@ def main():
         args.event_every = saved_every
         # (4) the fused C2 workload in rocRAND spawn mode (no host PCG64 schedule; statistically the same game,
         # bit-exact with the oracle's counter-based spawn, NOT with numba)
-        env3 = amd.VecGame(M, amd.reward_fn_normal, device=dev, spawn="rocrand", spawn_seed=args.seed)
-        env3.reset(args.seed)
-        for _ in range(3):
-            env3.rollout(N, masked=masked, act_seed=7)
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        reps = 50
-        for r in range(reps):
-            env3.rollout(N, masked=masked, act_seed=7, act_counter=(r + 3) * N)
-        torch.cuda.synchronize(dev)
-        d1 = time.perf_counter() - t1
-        extras["rocrand_spawn_mode"] = {"value": M * N * reps / d1, "unit": "board-steps/s", "ms_per_step": d1 / reps * 1e3,
-                                        "note": "spawn='rocrand': fused rollout with the rocRAND Philox spawn, no host "
-                                                "schedule; not bit-exact with the numba path (see DESIGN.md)"}
+        args.event_every = 8
+        sfn, stm, _e = make_fused(M, N, masked, "fused", args.schedule, seed_off=400, spawn="rocrand")
+        d1 = measure(sfn, 200, 20)
+        ms1 = timers_avg_ms(stm)
+        extras["rocrand_spawn_mode"] = {"value": M * N * 200 / d1, "unit": "board-steps/s", "ms_per_step": d1 / 200 * 1e3,
+                                        "roofline": rollout_roofline(M, N, ms1, masked, False, "rocrand"),
+                                        "note": "spawn='rocrand': fused rollout with the rocRAND Philox spawn (one word per "
+                                                "tile, one Philox block per four steps), no host schedule; not bit-exact "
+                                                "with the numba path, the same game statistically (see DESIGN.md)"}
+        del sfn, _e
+        args.event_every = saved_every
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -464,11 +464,12 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{tag}M={M} boards/GPU x N={N} random-action env steps per bench step "
                                    f"({'masked' if masked else 'unmasked'} uniform actions sampled on device, "
-                                   f"table spawn = bit-exact mode), {what}",
+                                   f"{'table spawn = bit-exact mode' if args.spawn == 'table' else 'rocRAND spawn mode'}), {what}",
                        "boards_per_gpu": M, "env_steps_per_step": N, "mode": args.mode, "sharding": f"replicas x{world}",
                        "host_schedule": args.schedule, "ML2048_HOST_THREADS": int(os.environ["ML2048_HOST_THREADS"]),
                        "per_rank": per_rank, "id_scan": args.ids,
-                       "spawn": "table (bit-exact with the reference's PCG64 tables)"},
+                       "spawn": "table (bit-exact with the reference's PCG64 tables)" if args.spawn == "table" else
+                                "rocrand (rocRAND Philox spawn: the same game statistically, not bit-exact with numba)"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         line.update(extras)

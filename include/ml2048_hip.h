@@ -104,11 +104,16 @@ int ml2048_step_wave(void *stream, int64_t M, int64_t idx_base, const ml2048_sta
                      int64_t row_base, const uint8_t *randperm, const float *randfloat);
 
 /*
- * Fast mode (no reference counterpart; NOT bit-exact with the numba path, statistically the same
- * game): the spawn uses rocRAND's Philox4x32-10 device generator keyed (seed; subsequence =
- * idx_base + idx; offset = 4 * counter) instead of the host PCG64 tables.  Cell = k-th empty cell,
- * k = (word0 * n_empty) >> 32; tile "2" iff word1 < ceil(two_prob * 2^32).  prepare uses words
- * 0..3 for its two tiles.  Bit-exact against oracle/ml2048_oracle.c orc_*_fast.
+ * rocRAND spawn mode (no reference counterpart; NOT bit-exact with the numba path, the same game
+ * statistically - tests/test_gpu_rocrand_stats.py): the spawn uses rocRAND's Philox4x32-10 device
+ * generator instead of the host PCG64 tables, ONE 32-bit word w per spawned tile:
+ *     cell = k-th empty cell in ascending order, k = ((w >> 16) * n_empty) >> 16;
+ *     tile "2" iff (w & 0xFFFF) < ceil(two_prob * 2^16).
+ * `counter` is the env's call counter c (0 for the first prepare / step after a reset, +1 per pair):
+ *     ml2048_step_fast     word c of the sequence keyed (seed; subsequence = idx_base + idx), so one Philox
+ *                          block serves four consecutive steps (the fused rollout computes it once per four);
+ *     ml2048_prepare_fast  words 2c and 2c+1 of the sequence keyed (seed ^ 0x9E3779B97F4A7C15; same subsequence).
+ * Bit-exact against oracle/ml2048_oracle.c orc_*_fast.
  */
 int ml2048_prepare_fast(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st,
                         double two_prob, uint64_t seed, uint64_t counter, int32_t *game_count,
@@ -359,9 +364,9 @@ int ml2048_rollout_traj(void *stream, int64_t M, int64_t idx_base, const ml2048_
                         uint64_t act_counter0, uint64_t *reset_flags, int32_t *last_reset,
                         const ml2048_traj *traj);
 
-/* The same fused rollout in fast (rocRAND) spawn mode: no host schedule at all.  Equals N calls of
- * ml2048_prepare_fast(counter = 2*(spawn_counter0+t)) / ml2048_sample_actions / ml2048_step_fast(
- * counter = 2*(spawn_counter0+t)+1); bit-exact against the oracle's orc_*_fast, not against numba. */
+/* The same fused rollout in rocRAND spawn mode: no host schedule at all.  Equals N calls of
+ * ml2048_prepare_fast(counter = spawn_counter0+t) / ml2048_sample_actions / ml2048_step_fast(
+ * counter = spawn_counter0+t); bit-exact against the oracle's orc_*_fast, not against numba. */
 int ml2048_rollout_fast(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
                         double two_prob, uint64_t spawn_seed, uint64_t spawn_counter0, int reward_kind,
                         int masked, uint64_t act_seed, uint64_t act_counter0, uint8_t *actions_out,

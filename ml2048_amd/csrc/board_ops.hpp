@@ -444,13 +444,18 @@ ML_HD void deal_table(Board &b, const uint32_t perm[4], uint32_t two_mask) {
     set_cell(b, c2, 2u - ubfe(two_mask, c2, 1));
 }
 
-// ---- counter-based spawn (fast mode; build-defined, equals oracle orc_step_fast) --------------
-// cell = k-th empty cell in ascending order, k = (a * n_empty) >> 32; tile 1 if b < thr else 2.
-ML_HD void spawn_counter(Board &b, uint32_t a, uint32_t bword, uint64_t thr) {
+// ---- counter-based spawn (spawn="rocrand"; build-defined, equals oracle orc_step_fast / orc_prepare_fast) ---------
+// ONE 32-bit word of the board's Philox sequence per spawned tile: its high half picks the k-th empty cell in ascending
+// order, k = (hi16 * n_empty) >> 16 (uniform over the empty cells up to 2^-16), its low half decides 2 vs 4 against
+// ceil(two_prob * 2^16).  A step consumes word c of the board's step stream (c = the env's step-call counter), so one
+// Philox block serves four consecutive steps - a fused rollout computes it once per four steps; the re-deal consumes
+// words 2c and 2c+1 of the deal stream (same key with kDealSeedXor).
+constexpr unsigned long long kDealSeedXor = 0x9E3779B97F4A7C15ull;
+ML_HD void spawn_word(Board &b, uint32_t w, uint32_t thr16) {
     uint32_t empties = empty_mask(b);
     uint32_t n_empty = (uint32_t)__builtin_popcount(empties);
     if (n_empty == 0) return;
-    uint32_t k = (uint32_t)(((uint64_t)a * n_empty) >> 32);
+    uint32_t k = ((w >> 16) * n_empty) >> 16;
     // position of the k-th (0-based) set bit of the 16-bit mask, by branch-free halving
     uint32_t m = empties, c = 0, cnt;
     cnt = (uint32_t)__builtin_popcount(m & 0xFFu);
@@ -461,7 +466,7 @@ ML_HD void spawn_counter(Board &b, uint32_t a, uint32_t bword, uint64_t thr) {
     if (k >= cnt) { k -= cnt; c += 2; m >>= 2; }
     cnt = m & 1u;
     if (k >= cnt) c += 1;
-    set_cell(b, c, ((uint64_t)bword < thr) ? 1u : 2u);
+    set_cell(b, c, ((w & 0xFFFFu) < thr16) ? 1u : 2u);
 }
 
 ML_HD uint32_t max_cell(const Board &b) {

@@ -103,6 +103,16 @@ __device__ __forceinline__ uint32_t rocrand_seq_word(uint64_t seed, uint64_t j, 
     const uint32_t k = (uint32_t)(j & 3ull); // wave-uniform
     return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
 }
+// the two words of re-deal call c (board_ops.hpp spawn_word): words 2c, 2c+1 of the deal stream - one Philox block
+__device__ __forceinline__ void rocrand_deal_words(uint64_t seed, uint64_t c, uint64_t idx, uint32_t &w0, uint32_t &w1) {
+    rocrand_state_philox4x32_10 s;
+    rocrand_init(seed ^ kDealSeedXor, idx, (2ull * c) & ~3ull, &s);
+    const uint4 v = rocrand4(&s);
+    const bool hi = ((2ull * c) & 2ull) != 0ull; // wave-uniform
+    w0 = hi ? v.z : v.x;
+    w1 = hi ? v.w : v.y;
+}
+
 // the draw of call-counter t, its bits at the bottom of the word: a masked draw takes W(t), a plain uniform
 // draw two bits of W(t >> 4)
 __device__ __forceinline__ uint32_t rocrand_sampler_word(uint64_t seed, uint64_t t, uint64_t idx, int masked) {

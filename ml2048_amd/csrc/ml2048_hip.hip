@@ -167,9 +167,7 @@ __global__ __launch_bounds__(kBlock) void k_step(ml2048_state st, int64_t M, int
         return;
     }
     if (FAST) {
-        uint32_t w[4];
-        rocrand_words(seed, counter, (uint64_t)(idx_base + i), w);
-        spawn_counter(s.board, w[0], w[1], thr);
+        spawn_word(s.board, rocrand_seq_word(seed, counter, (uint64_t)(idx_base + i)), (uint32_t)thr);
     } else {
         spawn_table(s.board, perm, two_mask, 1);
     }
@@ -390,10 +388,10 @@ __global__ __launch_bounds__(kPrepBlock) void k_prep_deal(ml2048_state st, int64
     StepRegs s;
     clear_regs(s); // entry.fill(0), game_numba.py:639
     if (FAST) {
-        uint32_t w[4];
-        rocrand_words(seed, counter, (uint64_t)(idx_base + i), w);
-        spawn_counter(s.board, w[0], w[1], thr);
-        spawn_counter(s.board, w[2], w[3], thr);
+        uint32_t w0, w1;
+        rocrand_deal_words(seed, counter, (uint64_t)(idx_base + i), w0, w1);
+        spawn_word(s.board, w0, (uint32_t)thr);
+        spawn_word(s.board, w1, (uint32_t)thr);
     } else {
         uint32_t perm[4];
         load_perm_row(randperm, row_base + idx_base + i, perm);
@@ -509,10 +507,10 @@ __global__ __launch_bounds__(kPrepBlock) void k_prep_fused(ml2048_state st, int6
     StepRegs s;
     clear_regs(s); // entry.fill(0), game_numba.py:639
     if (FAST) {
-        uint32_t w[4];
-        rocrand_words(seed, counter, (uint64_t)(idx_base + i), w);
-        spawn_counter(s.board, w[0], w[1], thr);
-        spawn_counter(s.board, w[2], w[3], thr);
+        uint32_t w0, w1;
+        rocrand_deal_words(seed, counter, (uint64_t)(idx_base + i), w0, w1);
+        spawn_word(s.board, w0, (uint32_t)thr);
+        spawn_word(s.board, w1, (uint32_t)thr);
     } else {
         uint32_t perm[4];
         load_perm_row(randperm, row_base + idx_base + i, perm);
@@ -577,10 +575,10 @@ __global__ __launch_bounds__(1024) void k_prep_small(ml2048_state st, int64_t M,
         StepRegs s;
         clear_regs(s);
         if (FAST) {
-            uint32_t w[4];
-            rocrand_words(seed, counter, (uint64_t)(idx_base + i), w);
-            spawn_counter(s.board, w[0], w[1], thr);
-            spawn_counter(s.board, w[2], w[3], thr);
+            uint32_t w0, w1;
+            rocrand_deal_words(seed, counter, (uint64_t)(idx_base + i), w0, w1);
+            spawn_word(s.board, w0, (uint32_t)thr);
+            spawn_word(s.board, w1, (uint32_t)thr);
         } else {
             uint32_t perm[4];
             load_perm_row(randperm, row_base + idx_base + i, perm);
@@ -858,6 +856,18 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
         }
     }
 
+    // spawn="rocrand": the step's spawn consumes word (spawn_counter0 + t) of the board's step stream (board_ops.hpp
+    // spawn_word), so one Philox block serves four steps; sw[0] is always the current word
+    uint32_t sw[4] = {0, 0, 0, 0};
+    if (FAST) {
+        rocrand_state_philox4x32_10 rs;
+        rocrand_init(spawn_seed, (uint64_t)(idx_base + ii), spawn_counter0 & ~3ull, &rs);
+        const uint4 v = rocrand4(&rs);
+        sw[0] = v.x; sw[1] = v.y; sw[2] = v.z; sw[3] = v.w;
+        for (uint32_t q = 0; q < (uint32_t)(spawn_counter0 & 3ull); ++q) { // wave-uniform, outside the loop
+            sw[0] = sw[1]; sw[1] = sw[2]; sw[2] = sw[3];
+        }
+    }
     // Everything that does not depend on game state is fetched ahead of its use - at M = 65 536 there is
     // one wave per SIMD and nobody else to hide a load behind (profiles/r01_i_sq_counters.json): the
     // schedule entry (scalar loads) two steps ahead, the two-mask and both permutation rows one step
@@ -982,6 +992,17 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                     rs1 = schedule[3 * j2 + 2];
                 }
 
+                if (FAST && t > 0) { // the next word of the step stream (wave-uniform)
+                    const uint64_t js = spawn_counter0 + (uint64_t)t;
+                    if ((js & 3ull) == 0) {
+                        rocrand_state_philox4x32_10 rs;
+                        rocrand_init(spawn_seed, (uint64_t)(idx_base + ii), js, &rs);
+                        const uint4 v = rocrand4(&rs);
+                        sw[0] = v.x; sw[1] = v.y; sw[2] = v.z; sw[3] = v.w;
+                    } else {
+                        sw[0] = sw[1]; sw[1] = sw[2]; sw[2] = sw[3];
+                    }
+                }
                 // ---- prepare (game_numba.py:619-658)
                 const bool deal = s.terminated != 0;
                 const unsigned long long dealt = __ballot(deal && live);
@@ -996,10 +1017,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                     mexp_first = mexp_second = 0;
                     merged_stale = true;
                     if (FAST) {
-                        uint32_t w4[4];
-                        rocrand_words(spawn_seed, 2ull * (spawn_counter0 + (uint64_t)t), (uint64_t)(idx_base + ii), w4);
-                        spawn_counter(s.board, w4[0], w4[1], thr);
-                        spawn_counter(s.board, w4[2], w4[3], thr);
+                        uint32_t w0, w1;
+                        rocrand_deal_words(spawn_seed, spawn_counter0 + (uint64_t)t, (uint64_t)(idx_base + ii), w0, w1);
+                        spawn_word(s.board, w0, (uint32_t)thr);
+                        spawn_word(s.board, w1, (uint32_t)thr);
                     } else {
                         const uint32_t head[4] = {perm_p, 0, 0, 0};
                         deal_table(s.board, head, two_mask);
@@ -1039,9 +1060,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                     merged_stale = true;
                     uint32_t empties = 0;
                     if (FAST) {
-                        uint32_t w4[4];
-                        rocrand_words(spawn_seed, 2ull * (spawn_counter0 + (uint64_t)t) + 1ull, (uint64_t)(idx_base + ii), w4);
-                        spawn_counter(s.board, w4[0], w4[1], thr);
+                        spawn_word(s.board, sw[0], (uint32_t)thr);
                     } else {
                         if (INV) empties = spawn_table_inv(s.board, perm_s, inv_s, two_mask);
                         else spawn_table(s.board, perm_s, two_mask, 1);
@@ -1397,10 +1416,11 @@ __global__ __launch_bounds__(kBlock) void k_gae(int64_t U, int64_t S, int64_t G,
     }
 }
 
+// spawn="rocrand": a tile is a 2 when the low half of its word is below ceil(two_prob * 2^16) (board_ops.hpp spawn_word)
 uint64_t two_threshold(double two_prob) {
-    double t = two_prob * 4294967296.0;
+    double t = two_prob * 65536.0;
     if (!(t > 0.0)) return 0;
-    if (t >= 4294967296.0) return 4294967296ull;
+    if (t >= 65536.0) return 65536ull;
     uint64_t c = (uint64_t)t;
     if ((double)c < t) c += 1;
     return c;

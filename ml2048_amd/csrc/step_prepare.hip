@@ -214,9 +214,7 @@ __global__ __launch_bounds__(kBlk) void k_step_prepare(const ml2048_step_prepare
         s.terminated = t_before;
         if (live && step_pre(s, action, a.reward_kind)) {
             if (FAST) {
-                uint32_t w[4];
-                rocrand_words(a.spawn_seed, a.spawn_counter_step, (uint64_t)(a.idx_base + i), w);
-                spawn_counter(s.board, w[0], w[1], thr);
+                spawn_word(s.board, rocrand_seq_word(a.spawn_seed, a.spawn_counter_step, (uint64_t)(a.idx_base + i)), (uint32_t)thr);
             } else {
                 spawn_table(s.board, perm, two_s, 1);
             }
@@ -280,10 +278,10 @@ __global__ __launch_bounds__(kBlk) void k_step_prepare(const ml2048_step_prepare
         if (live && term != 0) {
             clear_regs(s); // entry.fill(0), :639
             if (FAST) {
-                uint32_t w[4];
-                rocrand_words(a.spawn_seed, a.spawn_counter_prepare, (uint64_t)(a.idx_base + i), w);
-                spawn_counter(s.board, w[0], w[1], thr);
-                spawn_counter(s.board, w[2], w[3], thr);
+                uint32_t w0, w1;
+                rocrand_deal_words(a.spawn_seed, a.spawn_counter_prepare, (uint64_t)(a.idx_base + i), w0, w1);
+                spawn_word(s.board, w0, (uint32_t)thr);
+                spawn_word(s.board, w1, (uint32_t)thr);
             } else {
                 const uint32_t head[4] = {load_perm_head(a.randperm_prepare, a.row_base_prepare + a.idx_base + i), 0, 0, 0};
                 deal_table(s.board, head, two_p); // :648-655 on the zeroed board

@@ -562,7 +562,7 @@ class VecGame:
             else:
                 rc = L.ml2048_prepare_fast(
                     self._stream(), M, self._idx_base, self._st(), self._two_prob, self._spawn_seed,
-                    2 * self._fast_counter, self._game_count_dev.data_ptr(), self._n_reset_dev.data_ptr(),
+                    self._fast_counter, self._game_count_dev.data_ptr(), self._n_reset_dev.data_ptr(),
                     self._reset_indices.data_ptr(), self._scratch.data_ptr())
         _lib.check(rc, "prepare")
         self._serial += 1
@@ -605,7 +605,7 @@ class VecGame:
             else:
                 rc = L.ml2048_step_fast(self._stream(), M, self._idx_base, self._st(), a.data_ptr(),
                                         _ACT_CODE[a.dtype], self._reward_kind, self._two_prob, self._spawn_seed,
-                                        2 * self._fast_counter + 1)
+                                        self._fast_counter)
                 self._fast_counter += 1
         _lib.check(rc, "step")
         self._serial += 1
@@ -734,9 +734,9 @@ class VecGame:
                 A.two_mask_prepare = masks[e_p]
             else:
                 A.randperm_step = None
-                A.spawn_counter_step = 2 * self._fast_counter + 1
+                A.spawn_counter_step = self._fast_counter  # call counters (board_ops.hpp spawn_word)
                 self._fast_counter += 1
-                A.spawn_counter_prepare = 2 * self._fast_counter
+                A.spawn_counter_prepare = self._fast_counter
             if out is not self._sp_out:
                 for name, (shape, dts) in self.STEP_OUT_SPEC.items():
                     buf = None if out is None else out.get(name)

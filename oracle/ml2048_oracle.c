@@ -402,26 +402,37 @@ uint64_t orc_digest(const orc_record *data, int64_t M, int64_t idx_base, int wit
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* Fast-mode spawn: on-device counter-based RNG instead of the host PCG64 tables.  Build-defined
- * (the reference has no such mode); the HIP kernels' fast mode must equal this bit for bit.
- *   word pair (a, b): cell = k-th empty cell (ascending), k = (a * n_empty) >> 32;
- *                     tile = (b < ceil(two_prob * 2^32)) ? 1 : 2.                              */
-static inline uint64_t two_threshold(double two_prob) {
-    double t = ceil(two_prob * 4294967296.0);
+/* Fast-mode spawn (spawn="rocrand"): on-device counter-based RNG instead of the host PCG64 tables.  Build-defined
+ * (the reference has no such mode; it is the same GAME as _spawn2, game_numba.py:172-212: a uniformly random empty cell,
+ * a 2 with probability two_prob); the HIP kernels' fast mode must equal this bit for bit.
+ *   one 32-bit word w of the board's Philox4x32-10 sequence per spawned tile:
+ *       cell = k-th empty cell (ascending), k = ((w >> 16) * n_empty) >> 16;
+ *       tile = ((w & 0xFFFF) < ceil(two_prob * 2^16)) ? 1 : 2.
+ *   step call c:    word c of the sequence keyed (seed; subsequence = board index)   -> block c >> 2, word c & 3
+ *   re-deal call c: words 2c, 2c+1 of the sequence keyed (seed ^ 0x9E3779B97F4A7C15; board index)              */
+#define ORC_DEAL_SEED_XOR 0x9E3779B97F4A7C15ull
+static inline uint32_t two_threshold16(double two_prob) {
+    double t = ceil(two_prob * 65536.0);
     if (t <= 0.0) return 0;
-    if (t >= 4294967296.0) return 4294967296ull;
-    return (uint64_t)t;
+    if (t >= 65536.0) return 65536u;
+    return (uint32_t)t;
 }
 
-static inline void spawn_fast_one(uint8_t *board, uint32_t a, uint32_t b, uint64_t thr) {
+static inline uint32_t philox_seq_word(uint64_t seed, uint64_t j, uint64_t idx) {
+    uint32_t blk[4];
+    philox_at(seed, j >> 2, idx, blk);
+    return blk[j & 3u];
+}
+
+static inline void spawn_fast_one(uint8_t *board, uint32_t w, uint32_t thr16) {
     int n_empty = 0;
     for (int c = 0; c < 16; ++c) n_empty += board[c] == 0;
     if (n_empty == 0) return;
-    int k = (int)(((uint64_t)a * (uint64_t)n_empty) >> 32);
+    int k = (int)(((w >> 16) * (uint32_t)n_empty) >> 16);
     for (int c = 0; c < 16; ++c)
         if (board[c] == 0) {
             if (k == 0) {
-                board[c] = ((uint64_t)b < thr) ? 1 : 2;
+                board[c] = ((w & 0xFFFFu) < thr16) ? 1 : 2;
                 return;
             }
             --k;
@@ -431,7 +442,7 @@ static inline void spawn_fast_one(uint8_t *board, uint32_t a, uint32_t b, uint64
 void orc_step_fast(orc_record *data, int64_t M, int64_t idx_base, const void *actions,
                    int action_dtype, uint8_t *prev_state, uint8_t *prev_valid, int reward_kind,
                    double two_prob, uint64_t seed, uint64_t counter) {
-    const uint64_t thr = two_threshold(two_prob);
+    const uint32_t thr = two_threshold16(two_prob);
 #pragma omp parallel for schedule(static)
     for (int64_t idx = 0; idx < M; ++idx) {
         orc_record *e = &data[idx];
@@ -439,16 +450,14 @@ void orc_step_fast(orc_record *data, int64_t M, int64_t idx_base, const void *ac
         memcpy(prev_valid + idx * 4, e->valid_actions, 4);
         int64_t a = load_action(actions, action_dtype, idx);
         if (!step_one_pre(e, a, prev_state + idx * 16, reward_kind)) continue;
-        uint32_t r[4];
-        philox_at(seed, counter, (uint64_t)(idx_base + idx), r);
-        spawn_fast_one(e->board, r[0], r[1], thr);
+        spawn_fast_one(e->board, philox_seq_word(seed, counter, (uint64_t)(idx_base + idx)), thr);
         step_one_post(e);
     }
 }
 
 int64_t orc_prepare_fast(orc_record *data, int64_t M, int64_t idx_base, double two_prob,
                          uint64_t seed, uint64_t counter, int64_t *game_count, int64_t *indices) {
-    const uint64_t thr = two_threshold(two_prob);
+    const uint32_t thr = two_threshold16(two_prob);
     int64_t n = 0;
     for (int64_t idx = 0; idx < M; ++idx) {
         if (!data[idx].terminated) continue;
@@ -456,10 +465,8 @@ int64_t orc_prepare_fast(orc_record *data, int64_t M, int64_t idx_base, double t
         memset(e, 0, sizeof(*e));
         e->id = (int32_t)(*game_count);
         *game_count += 1;
-        uint32_t r[4];
-        philox_at(seed, counter, (uint64_t)(idx_base + idx), r);
-        spawn_fast_one(e->board, r[0], r[1], thr);
-        spawn_fast_one(e->board, r[2], r[3], thr);
+        spawn_fast_one(e->board, philox_seq_word(seed ^ ORC_DEAL_SEED_XOR, 2 * counter, (uint64_t)(idx_base + idx)), thr);
+        spawn_fast_one(e->board, philox_seq_word(seed ^ ORC_DEAL_SEED_XOR, 2 * counter + 1, (uint64_t)(idx_base + idx)), thr);
         orc_compute_valid_actions(e->board, e->valid_actions);
         if (indices) indices[n] = idx;
         ++n;

@@ -282,7 +282,7 @@ class OracleVecGame:
         else:
             n = lib().orc_prepare_fast(
                 _p(self._data), self._size, self._idx_base, self._two_prob,
-                C.c_uint64(self._fast_seed), C.c_uint64(2 * self._fast_counter), C.addressof(gc), _p(indices),
+                C.c_uint64(self._fast_seed), C.c_uint64(self._fast_counter), C.addressof(gc), _p(indices),
             )
         self._game_count = gc.value
         return (indices[:n].copy(),)
@@ -304,7 +304,7 @@ class OracleVecGame:
             lib().orc_step_fast(
                 _p(self._data), self._size, self._idx_base, _p(actions), _ACT_CODE[actions.dtype],
                 _p(self._prev_state), _p(self._prev_valid_actions), self._reward_kind, self._two_prob,
-                C.c_uint64(self._fast_seed), C.c_uint64(2 * self._fast_counter + 1),
+                C.c_uint64(self._fast_seed), C.c_uint64(self._fast_counter),
             )
             self._fast_counter += 1
         d = self._data

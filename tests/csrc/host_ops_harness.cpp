@@ -223,18 +223,18 @@ int64_t h_prepare(Rec *data, int64_t M, int64_t idx_base, int64_t row_base, cons
     return n;
 }
 
-static uint64_t thr_of(double two_prob) {
-    double t = two_prob * 4294967296.0;
+static uint32_t thr_of(double two_prob) { // ceil(two_prob * 2^16), clamped (board_ops.hpp spawn_word)
+    double t = two_prob * 65536.0;
     double c = (double)(uint64_t)t;
     if (c < t) c += 1.0;
     if (c <= 0.0) return 0;
-    if (c >= 4294967296.0) return 4294967296ull;
-    return (uint64_t)c;
+    if (c >= 65536.0) return 65536u;
+    return (uint32_t)c;
 }
 
 void h_step_fast(Rec *data, int64_t M, int64_t idx_base, const uint8_t *actions, uint8_t *prev_state,
                  uint8_t *prev_valid, int reward_kind, double two_prob, uint64_t seed, uint64_t counter) {
-    uint64_t thr = thr_of(two_prob);
+    const uint32_t thr = thr_of(two_prob);
     for (int64_t i = 0; i < M; ++i) {
         Rec &e = data[i];
         memcpy(prev_state + 16 * i, e.board, 16);
@@ -245,8 +245,7 @@ void h_step_fast(Rec *data, int64_t M, int64_t idx_base, const uint8_t *actions,
             e.invalid = 1;
             continue;
         }
-        U4 r = philox_at(seed, counter, (uint64_t)(idx_base + i));
-        spawn_counter(s.board, r.x, r.y, thr);
+        spawn_word(s.board, philox_seq_word(seed, counter, (uint64_t)(idx_base + i)), thr);
         step_post(s);
         store(e, s);
         e.invalid = 0;
@@ -255,16 +254,15 @@ void h_step_fast(Rec *data, int64_t M, int64_t idx_base, const uint8_t *actions,
 
 int64_t h_prepare_fast(Rec *data, int64_t M, int64_t idx_base, double two_prob, uint64_t seed,
                        uint64_t counter, int64_t *game_count) {
-    uint64_t thr = thr_of(two_prob);
+    const uint32_t thr = thr_of(two_prob);
     int64_t n = 0;
     for (int64_t i = 0; i < M; ++i) {
         Rec &e = data[i];
         if (!e.terminated) continue;
         StepRegs s;
         clear_regs(s);
-        U4 r = philox_at(seed, counter, (uint64_t)(idx_base + i));
-        spawn_counter(s.board, r.x, r.y, thr);
-        spawn_counter(s.board, r.z, r.w, thr);
+        spawn_word(s.board, philox_seq_word(seed ^ kDealSeedXor, 2 * counter, (uint64_t)(idx_base + i)), thr);
+        spawn_word(s.board, philox_seq_word(seed ^ kDealSeedXor, 2 * counter + 1, (uint64_t)(idx_base + i)), thr);
         s.valid = valid_actions(s.board);
         memset(&e, 0, sizeof(e));
         store(e, s);

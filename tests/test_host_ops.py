@@ -308,7 +308,7 @@ def test_fast_mode_matches_oracle(H, oracle):
     gc = C.c_int64(0)
     for s in range(N):
         (idx,) = env.prepare()
-        n = H.h_prepare_fast(_p(data), M, 0, 0.8, C.c_uint64(0xC0FFEE), C.c_uint64(2 * s), C.addressof(gc))
+        n = H.h_prepare_fast(_p(data), M, 0, 0.8, C.c_uint64(0xC0FFEE), C.c_uint64(s), C.addressof(gc))
         assert n == idx.size
         a_o, lp_o = oracle.sample_actions(env._data["valid_actions"], 77, s, masked=(s % 2 == 0))
         a_h = np.zeros(M, np.uint8)
@@ -319,7 +319,7 @@ def test_fast_mode_matches_oracle(H, oracle):
         assert np.array_equal(a_o, a_h)
         assert lp_o.tobytes() == lp_h.tobytes()
         env.step(a_o)
-        H.h_step_fast(_p(data), M, 0, _p(a_h), _p(prev_s), _p(prev_v), 1, 0.8, C.c_uint64(0xC0FFEE), C.c_uint64(2 * s + 1))
+        H.h_step_fast(_p(data), M, 0, _p(a_h), _p(prev_s), _p(prev_v), 1, 0.8, C.c_uint64(0xC0FFEE), C.c_uint64(s))
         assert data.tobytes() == env._data.tobytes(), s
         assert H.h_digest(_p(data), M, 0, 1) == env.digest()
         assert H.h_digest(_p(data), M, 0, 0) == env.digest(with_id=False)

@@ -53,5 +53,7 @@ if has sq; then
   sq_pass plain_large 262144 --boards 262144
   sq_pass masked_small 65536 --masked 1
   sq_pass masked_large 262144 --boards 262144 --masked 1
+  sq_pass rocrand_small 65536 --spawn rocrand
+  sq_pass rocrand_large 262144 --boards 262144 --spawn rocrand
 fi
 ls $OUT | head -50
