@@ -451,10 +451,11 @@ ML_HD void deal_table(Board &b, const uint32_t perm[4], uint32_t two_mask) {
 // Philox block serves four consecutive steps - a fused rollout computes it once per four steps; the re-deal consumes
 // words 2c and 2c+1 of the deal stream (same key with kDealSeedXor).
 constexpr unsigned long long kDealSeedXor = 0x9E3779B97F4A7C15ull;
-ML_HD void spawn_word(Board &b, uint32_t w, uint32_t thr16) {
-    uint32_t empties = empty_mask(b);
+// returns the emptiness mask before the spawn (bit c <=> cell c was empty; one bit set <=> the board is full now)
+ML_HD uint32_t spawn_word(Board &b, uint32_t w, uint32_t thr16) {
+    const uint32_t empties = empty_mask(b);
     uint32_t n_empty = (uint32_t)__builtin_popcount(empties);
-    if (n_empty == 0) return;
+    if (n_empty == 0) return 0u;
     uint32_t k = ((w >> 16) * n_empty) >> 16;
     // position of the k-th (0-based) set bit of the 16-bit mask, by branch-free halving
     uint32_t m = empties, c = 0, cnt;
@@ -467,6 +468,7 @@ ML_HD void spawn_word(Board &b, uint32_t w, uint32_t thr16) {
     cnt = m & 1u;
     if (k >= cnt) c += 1;
     set_cell(b, c, ((w & 0xFFFFu) < thr16) ? 1u : 2u);
+    return empties;
 }
 
 ML_HD uint32_t max_cell(const Board &b) {

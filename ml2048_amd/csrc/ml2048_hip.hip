@@ -1060,12 +1060,12 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                     merged_stale = true;
                     uint32_t empties = 0;
                     if (FAST) {
-                        spawn_word(s.board, sw[0], (uint32_t)thr);
+                        empties = spawn_word(s.board, sw[0], (uint32_t)thr);
                     } else {
                         if (INV) empties = spawn_table_inv(s.board, perm_s, inv_s, two_mask);
                         else spawn_table(s.board, perm_s, two_mask, 1);
                     }
-                    if (LAZY && INV && !FAST) step_post_lazy(s, empties);
+                    if (LAZY && (FAST || INV)) step_post_lazy(s, empties);
                     else if (LAZY) step_post_lazy(s);
                     else step_post(s);
                     invalid = 0;
