@@ -213,13 +213,31 @@ int ml2048_sched_stream_next(ml2048_sched_stream *s, const int32_t **schedule, c
                              int32_t *rand_step_after, const uint8_t **randperm_after,
                              const float **randfloat_after);
 int ml2048_sched_stream_release(ml2048_sched_stream *s);
-/* next() + release() with the schedule copied out in between, packed as the upload kernels expect:
- * dst (typically pinned host memory) receives [n_epochs x 1024 x 16 tables | int32[n_steps][3] padded to
- * 16 bytes | uint32[n_epochs] masks]; o_sched / o_mask / nbytes report the section offsets and the total
- * (rounded up to 16).  randperm_after (16 KiB) / randfloat_after (1024 floats) may be NULL.  Returns
- * ML2048_E_UNSUPPORTED without consuming anything when dst_capacity < *nbytes. */
+/*
+ * A slot of the stream holds one schedule in the layout the upload kernels read:
+ *     [ int32[n_steps][3] schedule, padded to 16 B | uint32[n_steps + 1] two-masks, padded | n_epochs x 1024 x 16 tables ]
+ * (ml2048_sched_stream_slot_bytes(n_steps) bytes at most).  create_pinned lets the CALLER provide the `depth` slot
+ * buffers - pinned host memory that a GPU copy kernel (ml2048_upload / ml2048_rollout_chain) reads in place, so that
+ * handing a schedule to the device copies nothing on the host:
+ *   take_slot   the next schedule in draw order, NOT released: *slot = which buffer, *n_epochs, *o_mask / *o_tab = byte
+ *               offsets of the masks / tables, *nbytes = bytes in use; the 20 KB of after-state (generator, counter,
+ *               tables after the schedule) are copied out (randperm_after / randfloat_after may be NULL).  Up to
+ *               depth schedules may be held at once (ML2048_E_UNSUPPORTED, nothing consumed, when every slot is held -
+ *               leave the producer a slot or two to work ahead in);
+ *   release     gives back the OLDEST held schedule, once nothing reads its slot any more.
+ * take = next() + a copy of the whole slot layout into dst + release(), for callers without pinned slots
+ * (ML2048_E_UNSUPPORTED, nothing consumed, when dst_capacity < *nbytes).
+ */
+int64_t ml2048_sched_stream_slot_bytes(int32_t n_steps);
+ml2048_sched_stream *ml2048_sched_stream_create_pinned(const ml2048_pcg64 *rng, const uint8_t *randperm,
+                                                       const float *randfloat, int32_t rand_step, int32_t n_steps,
+                                                       double two_prob, int32_t depth, void *const *slot_mem,
+                                                       int64_t slot_bytes);
+int ml2048_sched_stream_take_slot(ml2048_sched_stream *s, int32_t *slot, int32_t *n_epochs, int64_t *o_mask, int64_t *o_tab,
+                                  int64_t *nbytes, ml2048_pcg64 *rng_after, int32_t *rand_step_after,
+                                  uint8_t *randperm_after, float *randfloat_after);
 int ml2048_sched_stream_take(ml2048_sched_stream *s, void *dst, int64_t dst_capacity, int32_t *n_epochs,
-                             int64_t *o_sched, int64_t *o_mask, int64_t *nbytes, ml2048_pcg64 *rng_after,
+                             int64_t *o_mask, int64_t *o_tab, int64_t *nbytes, ml2048_pcg64 *rng_after,
                              int32_t *rand_step_after, uint8_t *randperm_after, float *randfloat_after);
 void ml2048_sched_stream_destroy(ml2048_sched_stream *s);
 
@@ -310,12 +328,12 @@ void ml2048_timer_destroy(void *timer);
  *    INVERSE in board layout (byte c = position of cell c), which lets the kernel find the first
  *    empty cell of the row with one shift per cell instead of probing 16 positions
  *    (csrc/board_ops.hpp spawn_table_inv; same tile as _spawn2, game_numba.py:172-212).  Such tables are
- *    produced by ml2048_upload / by the previous ml2048_rollout_chain (n_table_rows > 0).
+ *    produced by ml2048_upload / by the previous ml2048_rollout_chain (table_offset < nbytes).
  *  - the same launch copies the NEXT rollout's packed schedule: next_nbytes (rounded up to 16) from
- *    next_src_host (pinned / registered host memory, 16-byte aligned; its first next_table_rows x 16
- *    bytes are plain permutation rows) to next_dst (device, 16-byte aligned, not read by this launch),
- *    expanding those rows to the 32-byte form: next_dst receives next_table_rows x 32 bytes of tables
- *    followed by the remaining bytes unchanged.  Stream order alone then guarantees the data is there
+ *    next_src_host (pinned / registered host memory, 16-byte aligned - a schedule-stream slot: header, then from
+ *    byte next_table_offset on plain 16-byte permutation rows) to next_dst (device, 16-byte aligned, not read by this
+ *    launch), expanding those rows to the 32-byte form: next_dst receives the header unchanged and
+ *    2 x (next_nbytes - next_table_offset) bytes of tables behind it.  Stream order alone then guarantees the data is there
  *    for the next launch: a chain of fused rollouts needs no copy stream and no event.  next_* = NULL/0/0:
  *    no upload.  (The reference keeps its tables in host memory, game_numba.py:589-591: no counterpart.)
  */
@@ -324,17 +342,16 @@ int ml2048_rollout_chain(void *stream, int64_t M, int64_t idx_base, const ml2048
                          const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed,
                          uint64_t act_counter0, uint64_t *reset_flags, int32_t *last_reset,
                          const void *next_src_host, void *next_dst, int64_t next_nbytes,
-                         int64_t next_table_rows);
+                         int64_t next_table_offset);
 
 /*
  * Upload of a pre-drawn schedule: a copy KERNEL that reads device-accessible (pinned / registered)
  * host memory directly, so that the upload is an ordinary launch on `stream` and involves neither the
  * copy engine nor a host wait.  dst: device, src_host: pinned host memory, both 16-byte aligned; nbytes
- * is rounded up to a multiple of 16.  The first n_table_rows x 16 bytes are permutation rows and are
- * expanded to the 32-byte form described above (dst then needs nbytes + 16 x n_table_rows bytes);
- * n_table_rows = 0 is a plain copy.
+ * is rounded up to a multiple of 16.  The bytes from table_offset on are permutation rows and are expanded to the
+ * 32-byte form described above (dst then needs 2 x nbytes - table_offset bytes); table_offset = nbytes is a plain copy.
  */
-int ml2048_upload(void *stream, void *dst, const void *src_host, int64_t nbytes, int64_t n_table_rows);
+int ml2048_upload(void *stream, void *dst, const void *src_host, int64_t nbytes, int64_t table_offset);
 int ml2048_rollout(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
                    const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,
                    const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed,

@@ -102,6 +102,12 @@ _SIGNATURES = {
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.POINTER(Pcg64State),
                                            C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "ml2048_sched_stream_release": (C.c_int, [C.c_void_p]),
+    "ml2048_sched_stream_slot_bytes": (C.c_int64, [C.c_int32]),
+    "ml2048_sched_stream_create_pinned": (C.c_void_p, [C.POINTER(Pcg64State), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                                      C.c_double, C.c_int32, C.POINTER(C.c_void_p), C.c_int64]),
+    "ml2048_sched_stream_take_slot": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                                                C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(Pcg64State),
+                                                C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),
     "ml2048_sched_stream_take": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                            C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(Pcg64State),
                                            C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),

@@ -68,18 +68,20 @@ __device__ __forceinline__ uint32_t load_table_head(const uint8_t *tab, int64_t 
     return reinterpret_cast<const uint32_t *>(tab)[(row & (ML2048_RAND_SIZE - 1)) * (INV ? 8 : 4)];
 }
 
-// One 16-byte unit of a schedule upload.  The first `rows` units of the source are permutation rows:
-// each goes out as 32 bytes (the row, then its inverse); the rest (schedule, masks) is copied behind them.
-__device__ __forceinline__ void upload_unit(uint4 *dst, const uint4 *src, int64_t j, int64_t rows) {
+// One 16-byte unit of a schedule upload.  The source is a schedule-stream slot: [schedule | masks | epoch tables];
+// the units from `tab16` on are permutation rows: each goes out as 32 bytes (the row, then its inverse), the header
+// in front of them is copied unchanged (tab16 >= the number of units: a plain copy).
+__device__ __forceinline__ void upload_unit(uint4 *dst, const uint4 *src, int64_t j, int64_t tab16) {
     const uint4 v = src[j];
-    if (j < rows) {
+    if (j >= tab16) {
         const uint32_t perm[4] = {v.x, v.y, v.z, v.w};
         uint32_t inv[4];
         invert_perm_row(perm, inv);
-        dst[2 * j] = v;
-        dst[2 * j + 1] = make_uint4(inv[0], inv[1], inv[2], inv[3]);
+        const int64_t o = tab16 + 2 * (j - tab16);
+        dst[o] = v;
+        dst[o + 1] = make_uint4(inv[0], inv[1], inv[2], inv[3]);
     } else {
-        dst[j + rows] = v;
+        dst[j] = v;
     }
 }
 

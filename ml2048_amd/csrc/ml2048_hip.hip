@@ -52,7 +52,7 @@ struct ml2048_plain_launch {
     uint4 *up_dst;
     int64_t up_n16;
     unsigned up_blocks;
-    int64_t up_rows;
+    int64_t up_tab16;
 };
 __attribute__((visibility("hidden"))) int ml2048_internal_launch_rollout_plain_ilp(int reward_kind, bool fast, bool inv_tables,
                                                                                    const ml2048_plain_launch &a);
@@ -789,7 +789,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                                                     int32_t *__restrict__ last_reset, uint64_t spawn_seed,
                                                     uint64_t spawn_counter0, uint64_t thr, ml2048_traj traj,
                                                     const uint4 *__restrict__ up_src, uint4 *__restrict__ up_dst,
-                                                    int64_t up_n16, unsigned up_blocks, int64_t up_rows) {
+                                                    int64_t up_n16, unsigned up_blocks, int64_t up_tab16) {
     // The re-deal flags (one 64-bit ballot per step) of up to kFlagChunk steps are parked so that the step loop holds
     // no global store (its acknowledgement would share the vmcnt queue with the prefetched loads): in LDS, or - the
     // pass for small M, where a lone wave per SIMD pays for every slot - in a VGPR pair, step q of the chunk in lane q,
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
     // are gone after a few microseconds, so no board ever waits for a PCIe read.
     if (up_blocks > 0 && blockIdx.x >= gridDim.x - up_blocks) {
         const int64_t first = (int64_t)(blockIdx.x - (gridDim.x - up_blocks)) * kBlock + threadIdx.x;
-        for (int64_t j = first; j < up_n16; j += (int64_t)up_blocks * kBlock) upload_unit(up_dst, up_src, j, up_rows);
+        for (int64_t j = first; j < up_n16; j += (int64_t)up_blocks * kBlock) upload_unit(up_dst, up_src, j, up_tab16);
         return;
     }
 
@@ -1488,7 +1488,7 @@ int ML2048_ROLLOUT_PLAIN_TU(int reward_kind, bool fast, bool inv_tables, const m
                           a.idx_base, a.N, a.perm_epochs, a.two_masks, a.schedule, a.n_epochs, a.masked, a.act_seed,   \
                           a.act_counter0, (uint8_t *)nullptr, (uint64_t *)nullptr, a.reset_flags, a.flag_words,        \
                           a.last_reset, a.spawn_seed, a.spawn_counter0, a.two_threshold, traj, a.up_src, a.up_dst,     \
-                          a.up_n16, a.up_blocks, a.up_rows)
+                          a.up_n16, a.up_blocks, a.up_tab16)
 #define ML_PLAIN_KIND(K)                 \
     if (fast) {                          \
         ML_PLAIN(K, true, false);        \
@@ -1663,20 +1663,21 @@ int64_t ml2048_rollout_scratch_ints(int64_t M, int32_t N) {
 
 // schedule upload: 16 B per lane straight from device-accessible host memory
 __global__ __launch_bounds__(kBlock) void k_upload(uint4 *__restrict__ dst, const uint4 *__restrict__ src, int64_t n16,
-                                                   int64_t rows) {
+                                                   int64_t tab16) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += (int64_t)gridDim.x * kBlock)
-        upload_unit(dst, src, i, rows);
+        upload_unit(dst, src, i, tab16);
 }
 
-int ml2048_upload(void *stream, void *dst, const void *src_host, int64_t nbytes, int64_t n_table_rows) {
+int ml2048_upload(void *stream, void *dst, const void *src_host, int64_t nbytes, int64_t table_offset) {
     if (!dst || !src_host || nbytes <= 0) return fail(ML2048_E_INVALID, "dst/src_host/nbytes");
-    if (n_table_rows < 0 || n_table_rows * 16 > nbytes) return fail(ML2048_E_INVALID, "n_table_rows=%lld", (long long)n_table_rows);
+    if (table_offset < 0 || table_offset > nbytes || (table_offset < nbytes && (table_offset % 16 || (nbytes - table_offset) % 16)))
+        return fail(ML2048_E_INVALID, "table_offset=%lld (nbytes=%lld)", (long long)table_offset, (long long)nbytes);
     if (((uintptr_t)dst | (uintptr_t)src_host) % 16) return fail(ML2048_E_ALIGN, "dst and src_host must be 16-byte aligned");
     const int64_t n16 = (nbytes + 15) / 16;
     int64_t blocks = cdiv(n16, kBlock);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(k_upload, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, (uint4 *)dst,
-                       (const uint4 *)src_host, n16, n_table_rows);
+                       (const uint4 *)src_host, n16, table_offset >= nbytes ? n16 : table_offset / 16);
     return check_launch("ml2048_upload");
 }
 
@@ -1760,14 +1761,17 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
                           uint64_t *digests_out, uint64_t *reset_flags, int32_t *last_reset, uint64_t spawn_seed,
                           uint64_t spawn_counter0, double two_prob, const ml2048_traj *traj_or_null,
                           const void *up_src = nullptr, void *up_dst = nullptr, int64_t up_nbytes = 0,
-                          int64_t up_rows = 0, bool inv_tables = false) {
+                          int64_t up_table_offset = -1, bool inv_tables = false) {
     ml2048_traj traj = {};
-    if (up_rows < 0 || up_rows * 16 > up_nbytes) return fail(ML2048_E_INVALID, "next_table_rows=%lld", (long long)up_rows);
+    if (up_table_offset < 0) up_table_offset = up_nbytes; // no table units: a plain copy
+    if (up_table_offset > up_nbytes || (up_table_offset < up_nbytes && (up_table_offset % 16 || (up_nbytes - up_table_offset) % 16)))
+        return fail(ML2048_E_INVALID, "next_table_offset=%lld", (long long)up_table_offset);
     if (up_src || up_dst || up_nbytes) {
         if (!up_src || !up_dst || up_nbytes <= 0) return fail(ML2048_E_INVALID, "next_src_host/next_dst/next_nbytes");
         if (((uintptr_t)up_src | (uintptr_t)up_dst) % 16) return fail(ML2048_E_ALIGN, "next_src_host and next_dst must be 16-byte aligned");
     }
     const int64_t up_n16 = (up_nbytes + 15) / 16;
+    const int64_t up_tab16 = up_table_offset >= up_nbytes ? up_n16 : up_table_offset / 16;
     const unsigned up_blocks = up_n16 > 0 ? (unsigned)(cdiv(up_n16, kBlock) < 64 ? cdiv(up_n16, kBlock) : 64) : 0u;
     if (traj_or_null) {
         traj = *traj_or_null;
@@ -1794,7 +1798,7 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
         a.masked = masked, a.act_seed = act_seed, a.act_counter0 = act_counter0;
         a.reset_flags = reset_flags, a.flag_words = W, a.last_reset = last_reset;
         a.spawn_seed = spawn_seed, a.spawn_counter0 = spawn_counter0, a.two_threshold = thr;
-        a.up_src = (const uint4 *)up_src, a.up_dst = (uint4 *)up_dst, a.up_n16 = up_n16, a.up_blocks = up_blocks, a.up_rows = up_rows;
+        a.up_src = (const uint4 *)up_src, a.up_dst = (uint4 *)up_dst, a.up_n16 = up_n16, a.up_blocks = up_blocks, a.up_tab16 = up_tab16;
         if (M <= plain_ilp_max_boards() ? ml2048_internal_launch_rollout_plain_ilp(reward_kind, fast, inv_tables, a)
                                     : ml2048_internal_launch_rollout_plain_dflt(reward_kind, fast, inv_tables, a))
             return fail(ML2048_E_INVALID, "reward_kind=%d", reward_kind);
@@ -1804,7 +1808,7 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
     hipExtLaunchKernelGGL((k_rollout<K, F, true, false>), grid, block, 0, s, ev_start, ev_stop, 0, *st, M, idx_base, N, perm_epochs, two_masks, \
                        schedule, n_epochs, masked, act_seed, act_counter0, actions_out, digests_out,         \
                        reset_flags, W,                                                                       \
-                       last_reset, spawn_seed, spawn_counter0, thr, traj, (const uint4 *)up_src, (uint4 *)up_dst, up_n16, up_blocks, up_rows)
+                       last_reset, spawn_seed, spawn_counter0, thr, traj, (const uint4 *)up_src, (uint4 *)up_dst, up_n16, up_blocks, up_tab16)
 #define ML_KIND(F)                                                                   \
     switch (reward_kind) {                                                           \
     case ML2048_REWARD_NORMAL: ML_LAUNCH2(REWARD_NORMAL, F); break;                  \
@@ -1842,7 +1846,7 @@ int ml2048_rollout_chain(void *stream, int64_t M, int64_t idx_base, const ml2048
                          const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,
                          const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0,
                          uint64_t *reset_flags, int32_t *last_reset, const void *next_src_host, void *next_dst,
-                         int64_t next_nbytes, int64_t next_table_rows) {
+                         int64_t next_nbytes, int64_t next_table_offset) {
     if (int rc = check_state(M, st)) return rc;
     if (N <= 0 || n_epochs <= 0) return fail(ML2048_E_INVALID, "N=%d n_epochs=%d must be positive", N, n_epochs);
     if (!perm_epochs || !two_masks || !schedule || !reset_flags || !last_reset)
@@ -1851,7 +1855,7 @@ int ml2048_rollout_chain(void *stream, int64_t M, int64_t idx_base, const ml2048
     if (idx_base < 0) return fail(ML2048_E_INVALID, "idx_base must be >= 0");
     return launch_rollout((hipStream_t)stream, false, M, idx_base, st, N, perm_epochs, two_masks, schedule, n_epochs, reward_kind,
                           masked, act_seed, act_counter0, nullptr, nullptr, reset_flags, last_reset, 0, 0, 0.0, nullptr,
-                          next_src_host, next_dst, next_nbytes, next_table_rows, /*inv_tables=*/true);
+                          next_src_host, next_dst, next_nbytes, next_table_offset, /*inv_tables=*/true);
 }
 
 int ml2048_rollout_traj(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,

@@ -15,6 +15,7 @@ Differences from the reference, all deliberate and documented in DESIGN.md:
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import os
 from typing import Any, Optional, TypedDict
@@ -199,6 +200,9 @@ class VecGame:
         self._sdev = [None, None]   # device-side packed schedules (the resident one and the next one)
         self._sdev_i = 0
         self._la = None             # host-async: the NEXT schedule, already taken from the stream and uploaded
+        self._ss_mem = None         # pinned memory the schedule stream's slots live in (the GPU reads them in place)
+        self._ss_slots = None       # per slot: [pinned view, event of the launch that reads it, randperm after, randfloat after]
+        self._ss_held = collections.deque()  # slots handed out by take_slot and not released yet, oldest first
         self._sstream_after = None  # generator / counter / tables after the last CONSUMED schedule
         self._rng_on_device = False  # True while the device copy of the generator is the current one
         if step_mapping not in ("lane", "wave"):
@@ -313,6 +317,12 @@ class VecGame:
             return
         self._L.ml2048_sched_stream_destroy(self._sstream)
         self._sstream = None
+        # launches that still read a slot in place: the memory is reused by the next stream
+        for slot in self._ss_held:
+            if slot[1] is not None:
+                slot[1].synchronize()
+        self._ss_held.clear()
+        self._ss_slots = None
         self._la = None  # a schedule taken ahead of its rollout is simply dropped with the stream
         after = self._sstream_after
         self._sstream_after = None
@@ -330,12 +340,13 @@ class VecGame:
             self._tables_dirty = True
 
     def _pack_pinned(self, sched, epochs, masks, N: int):
-        """Pack [epoch tables | schedule | masks] (16-byte aligned sections) into the next pinned buffer of
-        the ring.  Returns (slot, layout): slot = [pinned tensor, event]; layout = (E, o_sched, o_mask, nbytes)."""
+        """Pack [schedule | masks | epoch tables] (16-byte aligned sections: the layout of a schedule-stream slot) into
+        the next pinned buffer of the ring.  Returns (slot, layout): slot = [pinned tensor, event]; layout = (E, o_mask,
+        o_tab, nbytes)."""
         E = int(epochs.shape[0])
-        o_sched = E * RAND_SIZE * 16
-        o_mask = o_sched + ((N * 12 + 15) // 16) * 16
-        nbytes = ((o_mask + E * 4 + 15) // 16) * 16
+        o_mask = ((N * 12 + 15) // 16) * 16
+        o_tab = o_mask + (((N + 1) * 4 + 15) // 16) * 16
+        nbytes = o_tab + E * RAND_SIZE * 16
         i = self._spin_i
         self._spin_i = (i + 1) % len(self._spin)
         slot = self._spin[i]
@@ -345,10 +356,12 @@ class VecGame:
             slot = [torch.empty((max(2 * nbytes, 1 << 19),), dtype=torch.uint8, pin_memory=True), None]
             self._spin[i] = slot
         packed = slot[0].numpy()
-        packed[:o_sched] = epochs.reshape(-1)
-        packed[o_sched:o_sched + N * 12] = sched.view(np.uint8).reshape(-1)
+        packed[:N * 12] = sched.view(np.uint8).reshape(-1)
+        packed[N * 12:o_mask] = 0
         packed[o_mask:o_mask + E * 4] = masks.view(np.uint8)
-        return slot, (E, o_sched, o_mask, nbytes)
+        packed[o_mask + E * 4:o_tab] = 0
+        packed[o_tab:nbytes] = epochs.reshape(-1)
+        return slot, (E, o_mask, o_tab, nbytes)
 
     def _dev_sched_buf(self, idx: int, nbytes: int) -> torch.Tensor:
         buf = self._sdev[idx]
@@ -369,18 +382,62 @@ class VecGame:
             s, inc = st["state"]["state"], st["state"]["inc"]
             m64 = (1 << 64) - 1
             c = _lib.Pcg64State(s >> 64, s & m64, inc >> 64, inc & m64, int(st["has_uint32"]), int(st["uinteger"]))
-            self._sstream = L.ml2048_sched_stream_create(C.byref(c), self._rng.randperm.ctypes.data,
-                                                         self._rng.randfloat.ctypes.data, self._rng.rand_step, N,
-                                                         self._two_prob, int(os.environ.get("ML2048_STREAM_DEPTH", "6")))
+            depth = int(os.environ.get("ML2048_STREAM_DEPTH", "8"))
+            sb = (int(L.ml2048_sched_stream_slot_bytes(N)) + 63) // 64 * 64
+            pinned = depth >= 4 and depth * sb <= (256 << 20) and os.environ.get("ML2048_STREAM_PINNED", "1") != "0"
+            if pinned:
+                # the stream's slots ARE the pinned staging buffers: the producer threads write a schedule where the
+                # upload kernels read it, and handing it over copies nothing (ml2048_sched_stream_take_slot)
+                if self._ss_mem is None or self._ss_mem.numel() < depth * sb:
+                    self._ss_mem = torch.empty((depth * sb,), dtype=torch.uint8, pin_memory=True)
+                mem = self._ss_mem
+                ptrs = (C.c_void_p * depth)(*[mem.data_ptr() + k * sb for k in range(depth)])
+                self._sstream = L.ml2048_sched_stream_create_pinned(
+                    C.byref(c), self._rng.randperm.ctypes.data, self._rng.randfloat.ctypes.data, self._rng.rand_step, N,
+                    self._two_prob, depth, ptrs, sb)
+                self._ss_slots = [[mem[k * sb:(k + 1) * sb], None, np.empty((RAND_SIZE, 16), np.uint8),
+                                   np.empty((RAND_SIZE,), np.float32)] for k in range(depth)]
+                self._ss_hold = max(2, depth - 3)  # slots left to the producer: the rest
+                self._ss_taken = 0
+            else:
+                self._sstream = L.ml2048_sched_stream_create(C.byref(c), self._rng.randperm.ctypes.data,
+                                                             self._rng.randfloat.ctypes.data, self._rng.rand_step, N,
+                                                             self._two_prob, depth)
+                self._ss_slots = None
             if not self._sstream:
                 raise _lib.Ml2048Error("ml2048_sched_stream_create failed")
             self._sstream_n = N
 
     def _take_schedule(self, N: int):
-        """The next schedule of the stream, packed straight into the next pinned buffer of the ring by ONE
-        native call (wait + three memcpy + release).  Returns (slot, (E, o_sched, o_mask, nbytes), after)."""
+        """The next schedule of the stream.  Returns (slot, (E, o_mask, o_tab, nbytes), after): slot[0] = the pinned
+        buffer that holds it as [schedule | masks | tables], slot[1] = the event of the launch that reads it (set by the
+        caller).  Pinned-slot streams hand the slot itself over (nothing copied but the 20 KB of after-state) and take
+        it back, oldest first, once that event has passed; otherwise ONE native call copies the schedule into the next
+        buffer of the staging ring."""
         L = self._L
         self._open_sched_stream(N)
+        ne, rs = C.c_int32(0), C.c_int32(0)
+        o_m, o_t, nb = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        after = _lib.Pcg64State()
+        if self._ss_slots is not None:
+            held = self._ss_held
+            while held and (len(held) >= self._ss_hold or (held[0][1] is not None and held[0][1].query())):
+                if held[0][1] is not None:
+                    held[0][1].synchronize()
+                held.popleft()[1] = None
+                _lib.check(L.ml2048_sched_stream_release(self._sstream), "sched_stream_release")
+            # slots are handed out round-robin; the after-state buffers belong to the slot INDEX (rewritten depth
+            # schedules later, when this schedule has long been executed)
+            slot = self._ss_slots[self._ss_taken % len(self._ss_slots)]
+            k = C.c_int32(-1)
+            rc = L.ml2048_sched_stream_take_slot(self._sstream, C.byref(k), C.byref(ne), C.byref(o_m), C.byref(o_t),
+                                                 C.byref(nb), C.byref(after), C.byref(rs), slot[2].ctypes.data,
+                                                 slot[3].ctypes.data)
+            _lib.check(rc, "sched_stream_take_slot")
+            assert self._ss_slots[k.value] is slot, (k.value, self._ss_taken)
+            self._ss_taken += 1
+            held.append(slot)
+            return slot, (int(ne.value), int(o_m.value), int(o_t.value), int(nb.value)), (after, rs.value, slot[2], slot[3])
         i = self._spin_i
         self._spin_i = (i + 1) % len(self._spin)
         slot = self._spin[i]
@@ -391,19 +448,16 @@ class VecGame:
             self._spin[i] = slot
         if len(slot) < 4:  # the generator / tables after this schedule, in buffers that live with the slot
             slot += [np.empty((RAND_SIZE, 16), np.uint8), np.empty((RAND_SIZE,), np.float32)]
-        ne, rs = C.c_int32(0), C.c_int32(0)
-        o_s, o_m, nb = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-        after = _lib.Pcg64State()
         while True:
-            rc = L.ml2048_sched_stream_take(self._sstream, slot[0].data_ptr(), slot[0].numel(), C.byref(ne), C.byref(o_s),
-                                            C.byref(o_m), C.byref(nb), C.byref(after), C.byref(rs),
+            rc = L.ml2048_sched_stream_take(self._sstream, slot[0].data_ptr(), slot[0].numel(), C.byref(ne), C.byref(o_m),
+                                            C.byref(o_t), C.byref(nb), C.byref(after), C.byref(rs),
                                             slot[2].ctypes.data, slot[3].ctypes.data)
             if rc == -3 and nb.value > slot[0].numel():  # unusually many epochs: a bigger pinned buffer
                 slot[0] = torch.empty((2 * nb.value,), dtype=torch.uint8, pin_memory=True)
                 continue
             _lib.check(rc, "sched_stream_take")
             break
-        return slot, (int(ne.value), int(o_s.value), int(o_m.value), int(nb.value)), (after, rs.value, slot[2], slot[3])
+        return slot, (int(ne.value), int(o_m.value), int(o_t.value), int(nb.value)), (after, rs.value, slot[2], slot[3])
 
     def _pull_rng(self, sync_lookahead: bool = True) -> None:
         """Make the host generator current again (before any host-side draw or inspection)."""
@@ -682,7 +736,7 @@ class VecGame:
         slot[0].numpy()[:nbytes] = tabs.reshape(-1)
         # the previous block's device array goes back to the caching allocator, whose reuse is ordered on this stream
         self._sp_block_dev = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
-        _lib.check(self._L.ml2048_upload(self._stream(), self._sp_block_dev.data_ptr(), slot[0].data_ptr(), nbytes, 0),
+        _lib.check(self._L.ml2048_upload(self._stream(), self._sp_block_dev.data_ptr(), slot[0].data_ptr(), nbytes, nbytes),
                    "upload")
         if slot[1] is None:
             slot[1] = torch.cuda.Event()
@@ -942,44 +996,45 @@ class VecGame:
             staged = []  # pinned slots read by this rollout's launches: released by its event
             expand = asyn and plain
 
-            def dev_layout(E, o_sched, o_mask, nbytes):
-                grow = E * RAND_SIZE * 16 if expand else 0   # the inverse rows
-                return {"E": E, "o_sched": o_sched + grow, "o_mask": o_mask + grow, "nbytes": nbytes + grow,
-                        "rows": E * RAND_SIZE if expand else 0, "inv": expand}
+            def dev_layout(E, o_mask, o_tab, nbytes):
+                # device copy: [schedule | masks | tables], the tables with their inverse rows when expanded
+                return {"E": E, "o_mask": o_mask, "o_tab": o_tab, "host_nbytes": nbytes,
+                        "nbytes": nbytes + (nbytes - o_tab if expand else 0),
+                        "tab": o_tab if expand else nbytes, "inv": expand}
 
             with self._dev_ctx():
                 if cur is None:
                     if asyn:
-                        pslot, (E, o_sched, o_mask, nbytes), after_state = self._take_schedule(N)
+                        pslot, lay, after_state = self._take_schedule(N)
                     else:
                         sched, epochs, masks = self._next_schedule(N)
                         after_state = None
                         if prefetch_next:
                             self._start_prefetch(N)  # the NEXT schedule, on a worker thread (sync mode)
-                        pslot, (E, o_sched, o_mask, nbytes) = self._pack_pinned(sched, epochs, masks, N)
-                    cur = dev_layout(E, o_sched, o_mask, nbytes)
+                        pslot, lay = self._pack_pinned(sched, epochs, masks, N)
+                    cur = dev_layout(*lay)
                     self._sdev_i ^= 1
                     dbuf = self._dev_sched_buf(self._sdev_i, cur["nbytes"])
-                    _lib.check(L.ml2048_upload(self._stream(join=False), dbuf.data_ptr(), pslot[0].data_ptr(), nbytes,
-                                               cur["rows"]), "upload")
+                    _lib.check(L.ml2048_upload(self._stream(join=False), dbuf.data_ptr(), pslot[0].data_ptr(),
+                                               cur["host_nbytes"], cur["tab"]), "upload")
                     staged.append(pslot)
                     cur.update({"N": N, "idx": self._sdev_i, "after": after_state})
-                E, o_sched, o_mask = cur["E"], cur["o_sched"], cur["o_mask"]
+                E, o_mask, o_tab = cur["E"], cur["o_mask"], cur["o_tab"]
                 packed_dev = self._sdev[cur["idx"]]
                 chain = None
                 if expand:
                     # take the next schedule now and let this launch upload (and expand) it
-                    nslot, (E2, o_sched2, o_mask2, nbytes2), after_next = self._take_schedule(N)
-                    nxt = dev_layout(E2, o_sched2, o_mask2, nbytes2)
+                    nslot, lay2, after_next = self._take_schedule(N)
+                    nxt = dev_layout(*lay2)
                     ndev = self._dev_sched_buf(cur["idx"] ^ 1, nxt["nbytes"])
-                    chain = (nslot, ndev, nbytes2, nxt["rows"])
+                    chain = (nslot, ndev, nxt["host_nbytes"], nxt["tab"])
                     staged.append(nslot)
                     nxt.update({"N": N, "idx": cur["idx"] ^ 1, "after": after_next})
                     self._la = nxt
             if asyn:
                 self._sstream_after = cur["after"]  # what _close_sched_stream re-synchronises the generator to
-            perm_dev = packed_dev[:o_sched]
-            sched_dev = packed_dev[o_sched:o_sched + N * 12]
+            perm_dev = packed_dev[o_tab:cur["nbytes"]]
+            sched_dev = packed_dev[:N * 12]
             mask_dev = packed_dev[o_mask:o_mask + E * 4]
             if E > 1:
                 self._tables_dirty = True  # device copies of the tables are refreshed lazily (per-step API)
@@ -1047,7 +1102,7 @@ class VecGame:
                 # ONE marker per rollout, right after its kernel: it frees the pinned buffers the launch
                 # read and is what a deferred id scan waits for (every marker costs GPU time between kernels)
                 if self._roll_ev is None:
-                    self._roll_ev = [torch.cuda.Event() for _ in range(len(self._spin))]
+                    self._roll_ev = [torch.cuda.Event() for _ in range(16)]  # more than any ring / slot count that refers to them
                 roll_ev = self._roll_ev[self._roll_i]
                 self._roll_i = (self._roll_i + 1) % len(self._roll_ev)
                 roll_ev.record(torch.cuda.current_stream(dev))

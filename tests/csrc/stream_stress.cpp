@@ -3,6 +3,9 @@
 // workers are preempted at arbitrary points (between publishing a range and anything that follows it - the window
 // in which a per-slot completion count used to land on the slot's next occupant and strand the consumer).
 // Every delivered schedule is compared with the synchronous ml2048_hostrng_schedule on the same generator state.
+// With a fourth argument "slots" the consumer is the zero-copy one (create_pinned + take_slot): it holds up to three
+// schedules in caller-provided slot memory, hashes each again when it releases it (a producer that wrote into a held
+// slot would change it - and race, which the -fsanitize=thread build reports).
 // Built by tests/test_stream_stress.py twice: plain -O2, and -fsanitize=thread without OpenMP (libgomp is not
 // instrumented; the stream itself uses std::thread only).  A hang is caught by the test's timeout.
 #include <stdint.h>
@@ -67,10 +70,57 @@ int main(int argc, char **argv) {
                 if ((x >> 60) == 0) std::this_thread::yield();
             }
         });
-    ml2048_sched_stream *h = ml2048_sched_stream_create(&st0, perm0.data(), flt0.data(), 0, n_steps, 0.8, 3);
-    if (!h) return puts("create failed"), 1;
+    const bool slots_mode = argc > 4 && !strcmp(argv[4], "slots");
     int bad = 0;
     uint64_t lcg = 12345;
+    if (slots_mode) {
+        const int depth = 5;
+        const int64_t sb = ml2048_sched_stream_slot_bytes(n_steps);
+        std::vector<std::vector<uint8_t>> mem((size_t)depth, std::vector<uint8_t>((size_t)sb + 16));
+        void *ptrs[depth];
+        for (int d = 0; d < depth; ++d) ptrs[d] = mem[(size_t)d].data() + (16 - (uintptr_t)mem[(size_t)d].data() % 16) % 16;
+        ml2048_sched_stream *h = ml2048_sched_stream_create_pinned(&st0, perm0.data(), flt0.data(), 0, n_steps, 0.8, depth, ptrs, sb);
+        if (!h) return puts("create_pinned failed"), 1;
+        struct Held { int slot; int64_t nbytes; uint64_t hash; };
+        std::vector<Held> held;
+        auto release_oldest = [&] {
+            const Held hd = held.front();
+            held.erase(held.begin());
+            if (fnv(ptrs[hd.slot], (size_t)hd.nbytes, 1) != hd.hash) puts("a held slot was rewritten"), bad = 1;
+            if (ml2048_sched_stream_release(h) != 0) puts("release failed"), bad = 1;
+        };
+        for (int k = 0; k < iters && !bad; ++k) {
+            int32_t slot = -1, E = 0, rs = 0;
+            int64_t o_mask = 0, o_tab = 0, nbytes = 0;
+            ml2048_pcg64 after;
+            if (held.size() >= 3) release_oldest();
+            if (ml2048_sched_stream_take_slot(h, &slot, &E, &o_mask, &o_tab, &nbytes, &after, &rs, nullptr, nullptr) != 0) {
+                puts("take_slot failed");
+                bad = 1;
+                break;
+            }
+            const uint8_t *b = (const uint8_t *)ptrs[slot];
+            uint64_t g = fnv(b, (size_t)n_steps * 12, 0xCBF29CE484222325ull);
+            g = fnv(b + o_tab, (size_t)E * ML2048_RAND_SIZE * 16, g);
+            g = fnv(b + o_mask, (size_t)E * 4, g);
+            g = fnv(&after, sizeof after, g);
+            g = fnv(&rs, 4, g);
+            if (g != want[(size_t)k]) printf("schedule %d differs from the synchronous one\n", k), bad = 1;
+            held.push_back({slot, nbytes, fnv(b, (size_t)nbytes, 1)});
+            lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+            if ((lcg >> 61) == 0) std::this_thread::sleep_for(std::chrono::microseconds((lcg >> 40) & 255));
+            if ((lcg >> 59) == 1 && !held.empty()) release_oldest(); // sometimes run with fewer held
+        }
+        while (!held.empty() && !bad) release_oldest();
+        ml2048_sched_stream_destroy(h);
+        stop.store(true);
+        for (auto &t : burn) t.join();
+        if (bad) return 1;
+        printf("stream stress ok (slots): %d schedules of %d steps, %d burner threads\n", iters, n_steps, burners);
+        return 0;
+    }
+    ml2048_sched_stream *h = ml2048_sched_stream_create(&st0, perm0.data(), flt0.data(), 0, n_steps, 0.8, 3);
+    if (!h) return puts("create failed"), 1;
     for (int k = 0; k < iters && !bad; ++k) {
         const int32_t *sched;
         const uint8_t *epochs, *perm_after;

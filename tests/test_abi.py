@@ -60,7 +60,8 @@ def test_argument_validation_without_gpu(lib):
     ok = _lib.State(*([4096] * 11))
     assert lib.ml2048_upload(None, None, None, 0, 0) == -1
     assert lib.ml2048_upload(None, 4096, 4104, 64, 0) == -2              # src not 16-byte aligned
-    assert lib.ml2048_upload(None, 4096, 8192, 64, 5) == -1              # more table rows than bytes
+    assert lib.ml2048_upload(None, 4096, 8192, 64, 80) == -1             # tables beyond the end
+    assert lib.ml2048_upload(None, 4096, 8192, 64, 24) == -1             # table section not in 16-byte rows
     assert lib.ml2048_rollout_chain(None, 64, 0, C.byref(ok), 8, None, None, 1, None, 0, 0, 0, 0, None, None,
                                     None, None, 0, 0) == -1
     assert lib.ml2048_rollout_chain(None, 64, 0, C.byref(ok), 8, 4096, 4096, 1, 4096, 0, 0, 0, 0, 4096, 4096,
@@ -73,6 +74,10 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ml2048_timer_arm(None) == -1 and lib.ml2048_timer_elapsed_ms(None, None) == -1
     lib.ml2048_timer_destroy(None)
     assert lib.ml2048_sched_stream_take(None, None, 0, None, None, None, None, None, None, None, None) == -1
+    assert lib.ml2048_sched_stream_take_slot(None, None, None, None, None, None, None, None, None, None) == -1
+    assert lib.ml2048_sched_stream_slot_bytes(0) == 0
+    assert lib.ml2048_sched_stream_slot_bytes(128) == 1536 + 528 + 129 * 1024 * 16
+    assert not lib.ml2048_sched_stream_create_pinned(None, None, None, 0, 128, 0.8, 4, None, 0)
     # the one-launch step: one argument struct, checked field by field before any launch
     assert lib.ml2048_step_prepare(None, None) == -1
     A = _lib.StepPrepareArgs()

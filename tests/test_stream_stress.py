@@ -29,8 +29,11 @@ def test_stream_oversubscribed_matches_sync(tmp_path):
     exe = _build(tmp_path, "stream_stress", ["-O2", "-fopenmp"])
     _run(exe, 6000, 8)
     _run(exe, 300, 128)
+    _run(exe, 3000, 8, os.cpu_count() or 8, "slots")   # the zero-copy consumer: several schedules held in caller memory
+    _run(exe, 300, 128, os.cpu_count() or 8, "slots")
 
 
 def test_stream_under_thread_sanitizer(tmp_path):
     exe = _build(tmp_path, "stream_stress_tsan", ["-O1", "-g", "-fsanitize=thread"])
     _run(exe, 600, 8, 4)
+    _run(exe, 600, 8, 4, "slots")
