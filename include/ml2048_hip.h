@@ -30,6 +30,7 @@ extern "C" {
 
 #define ML2048_ABI_VERSION 1
 #define ML2048_RAND_SIZE 1024 /* VecGame._RAND_SIZE, game_numba.py:533 */
+#define ML2048_EXPANDED_ROW_BYTES 48 /* a permutation row as ml2048_rollout_chain reads it */
 
 enum { ML2048_E_INVALID = -1, ML2048_E_ALIGN = -2, ML2048_E_UNSUPPORTED = -3 };
 enum { ML2048_REWARD_NORMAL = 0, ML2048_REWARD_IMPROVED = 1, ML2048_REWARD_RANK = 2, ML2048_REWARD_MAXCELL = 3 };
@@ -274,8 +275,8 @@ int ml2048_devrng_schedule(void *stream, const void *workspace, ml2048_devrng *r
  * wavefront that follows the draw order with one table look-up per regeneration, and row-parallel swaps.
  * Same arguments and results as ml2048_devrng_schedule; workspace: ml2048_devrng2_workspace_bytes() bytes,
  * 256-byte aligned, prepared once by ml2048_devrng2_init (the schedule call reuses it as scratch).
- * expanded_tables != 0: perm_epochs is uint8[max_epochs][1024][32] - each row followed by its inverse
- * permutation in board layout, the table form ml2048_rollout_chain consumes.
+ * expanded_tables != 0: perm_epochs is uint8[max_epochs][1024][48] - ML2048_EXPANDED_ROW_BYTES per row, the table
+ * form ml2048_rollout_chain consumes (described there).
  * On a non-NULL stream the dozen dependent launches of one call are captured once per argument set into a
  * hipGraph (the library keeps the last 96) and replayed with one hipGraphLaunch; calls with repeating
  * arguments (a ring of output buffers) therefore cost one enqueue.  ML2048_DEVRNG_GRAPH=0 in the environment
@@ -324,16 +325,18 @@ void ml2048_timer_destroy(void *timer);
 
 /*
  * The pipelined form of ml2048_rollout: expanded tables + chained upload.
- *  - perm_epochs is uint8[n_epochs][1024][32]: each row is the 16-byte permutation followed by its
- *    INVERSE in board layout (byte c = position of cell c), which lets the kernel find the first
- *    empty cell of the row with one shift per cell instead of probing 16 positions
- *    (csrc/board_ops.hpp spawn_table_inv; same tile as _spawn2, game_numba.py:172-212).  Such tables are
- *    produced by ml2048_upload / by the previous ml2048_rollout_chain (table_offset < nbytes).
+ *  - perm_epochs is uint8[n_epochs][1024][ML2048_EXPANDED_ROW_BYTES = 48]: an EXPANDED row is twelve 32-bit words
+ *    {the permutation as sixteen nibbles (2 words), 0, 0, wlo[4], whi[4]}, where byte c of the weight vectors
+ *    (board layout) is 2^p for the position p of cell c in the row - in wlo when p < 8, as 2^(p-8) in whi otherwise.
+ *    "Which positions of the row hold an empty cell" is then a dot product of the board's emptiness flags with the
+ *    weights (eight v_dot4_u32_u8 instead of probing sixteen positions; csrc/board_ops.hpp spawn_table_dot /
+ *    expand_perm_row; same tile as _spawn2, game_numba.py:172-212).  Such tables are produced by ml2048_upload / by
+ *    the previous ml2048_rollout_chain (table_offset < nbytes) and by ml2048_devrng*_schedule (expanded_tables).
  *  - the same launch copies the NEXT rollout's packed schedule: next_nbytes (rounded up to 16) from
  *    next_src_host (pinned / registered host memory, 16-byte aligned - a schedule-stream slot: header, then from
  *    byte next_table_offset on plain 16-byte permutation rows) to next_dst (device, 16-byte aligned, not read by this
- *    launch), expanding those rows to the 32-byte form: next_dst receives the header unchanged and
- *    2 x (next_nbytes - next_table_offset) bytes of tables behind it.  Stream order alone then guarantees the data is there
+ *    launch), expanding those rows to the 48-byte form: next_dst receives the header unchanged and
+ *    3 x (next_nbytes - next_table_offset) bytes of tables behind it.  Stream order alone then guarantees the data is there
  *    for the next launch: a chain of fused rollouts needs no copy stream and no event.  next_* = NULL/0/0:
  *    no upload.  (The reference keeps its tables in host memory, game_numba.py:589-591: no counterpart.)
  */
@@ -349,7 +352,8 @@ int ml2048_rollout_chain(void *stream, int64_t M, int64_t idx_base, const ml2048
  * host memory directly, so that the upload is an ordinary launch on `stream` and involves neither the
  * copy engine nor a host wait.  dst: device, src_host: pinned host memory, both 16-byte aligned; nbytes
  * is rounded up to a multiple of 16.  The bytes from table_offset on are permutation rows and are expanded to the
- * 32-byte form described above (dst then needs 2 x nbytes - table_offset bytes); table_offset = nbytes is a plain copy.
+ * 48-byte form described above (dst then needs table_offset + 3 x (nbytes - table_offset) bytes); table_offset = nbytes
+ * is a plain copy.
  */
 int ml2048_upload(void *stream, void *dst, const void *src_host, int64_t nbytes, int64_t table_offset);
 int ml2048_rollout(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,

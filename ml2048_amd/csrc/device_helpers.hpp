@@ -48,16 +48,21 @@ __device__ __forceinline__ uint32_t load_perm_head(const uint8_t *randperm, int6
     return reinterpret_cast<const uint32_t *>(randperm)[(row & (ML2048_RAND_SIZE - 1)) * 4];
 }
 
-// INV tables: a row is 32 bytes - the permutation, then its inverse in board layout (board_ops.hpp
-// spawn_table_inv); ROW16 = uint4 units per row
+// INV tables hold EXPANDED rows (board_ops.hpp expand_perm_row / spawn_table_dot): 48 bytes = three uint4 units
+// {permutation as nibbles, 0, 0}, {low-byte weights}, {high-byte weights}.  With INV, perm[0..1] receive the nibbles and
+// wlo / whi the weights; without, perm[] is the plain 16-byte row.
+constexpr int kExpandedRowUnits = 3;
 template <bool INV>
-__device__ __forceinline__ void load_table_row(const uint8_t *tab, int64_t row, uint32_t perm[4], uint32_t inv[4]) {
+__device__ __forceinline__ void load_table_row(const uint8_t *tab, int64_t row, uint32_t perm[4], uint32_t wlo[4],
+                                               uint32_t whi[4]) {
     const uint4 *t = reinterpret_cast<const uint4 *>(tab);
     const int64_t r = row & (ML2048_RAND_SIZE - 1);
     if (INV) {
-        const uint4 v = t[2 * r], w = t[2 * r + 1];
-        perm[0] = v.x; perm[1] = v.y; perm[2] = v.z; perm[3] = v.w;
-        inv[0] = w.x; inv[1] = w.y; inv[2] = w.z; inv[3] = w.w;
+        const uint2 p = *reinterpret_cast<const uint2 *>(t + kExpandedRowUnits * r);
+        const uint4 v = t[kExpandedRowUnits * r + 1], w = t[kExpandedRowUnits * r + 2];
+        perm[0] = p.x; perm[1] = p.y;
+        wlo[0] = v.x; wlo[1] = v.y; wlo[2] = v.z; wlo[3] = v.w;
+        whi[0] = w.x; whi[1] = w.y; whi[2] = w.z; whi[3] = w.w;
     } else {
         const uint4 v = t[r];
         perm[0] = v.x; perm[1] = v.y; perm[2] = v.z; perm[3] = v.w;
@@ -65,21 +70,25 @@ __device__ __forceinline__ void load_table_row(const uint8_t *tab, int64_t row, 
 }
 template <bool INV>
 __device__ __forceinline__ uint32_t load_table_head(const uint8_t *tab, int64_t row) {
-    return reinterpret_cast<const uint32_t *>(tab)[(row & (ML2048_RAND_SIZE - 1)) * (INV ? 8 : 4)];
+    return reinterpret_cast<const uint32_t *>(tab)[(row & (ML2048_RAND_SIZE - 1)) * (INV ? 4 * kExpandedRowUnits : 4)];
+}
+
+__device__ __forceinline__ void store_expanded_row(uint4 *dst, const uint32_t perm[4]) {
+    uint32_t x[kExpandedRowWords];
+    expand_perm_row(perm, x);
+    dst[0] = make_uint4(x[0], x[1], x[2], x[3]);
+    dst[1] = make_uint4(x[4], x[5], x[6], x[7]);
+    dst[2] = make_uint4(x[8], x[9], x[10], x[11]);
 }
 
 // One 16-byte unit of a schedule upload.  The source is a schedule-stream slot: [schedule | masks | epoch tables];
-// the units from `tab16` on are permutation rows: each goes out as 32 bytes (the row, then its inverse), the header
-// in front of them is copied unchanged (tab16 >= the number of units: a plain copy).
+// the units from `tab16` on are permutation rows: each goes out as a 48-byte expanded row, the header in front of
+// them is copied unchanged (tab16 >= the number of units: a plain copy).
 __device__ __forceinline__ void upload_unit(uint4 *dst, const uint4 *src, int64_t j, int64_t tab16) {
     const uint4 v = src[j];
     if (j >= tab16) {
         const uint32_t perm[4] = {v.x, v.y, v.z, v.w};
-        uint32_t inv[4];
-        invert_perm_row(perm, inv);
-        const int64_t o = tab16 + 2 * (j - tab16);
-        dst[o] = v;
-        dst[o + 1] = make_uint4(inv[0], inv[1], inv[2], inv[3]);
+        store_expanded_row(dst + tab16 + kExpandedRowUnits * (j - tab16), perm);
     } else {
         dst[j] = v;
     }

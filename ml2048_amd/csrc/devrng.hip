@@ -109,16 +109,18 @@ __device__ __forceinline__ void lds_barrier() {
 // ran out before step N (more than ~23 regenerations in 128 steps: rare, but it happens): cont[0] = epochs so
 // far, cont[1] = error, cont[4] = steps already done, cont[5] = "ran out" flag.  This kernel then finishes steps
 // cont[4]..N-1 from the generator state the other one left; when nothing is left it returns at once.
-// EXPANDED: 32-byte epoch rows (permutation + inverse) as ml2048_rollout_chain consumes them.
+// EXPANDED: 48-byte epoch rows (board_ops.hpp expand_perm_row) as ml2048_rollout_chain consumes them.
 template <bool EXPANDED>
 __device__ __forceinline__ void store_epoch_row1(uint8_t *perm_epochs, size_t epoch, int t, uint4 v) {
     uint4 *out = reinterpret_cast<uint4 *>(perm_epochs);
     if (EXPANDED) {
         const uint32_t perm[4] = {v.x, v.y, v.z, v.w};
-        uint32_t inv[4];
-        ml2048::invert_perm_row(perm, inv);
-        out[2 * (epoch * kThreads + t)] = v;
-        out[2 * (epoch * kThreads + t) + 1] = make_uint4(inv[0], inv[1], inv[2], inv[3]);
+        uint32_t x[ml2048::kExpandedRowWords];
+        ml2048::expand_perm_row(perm, x);
+        uint4 *row = out + 3 * (epoch * kThreads + t);
+        row[0] = make_uint4(x[0], x[1], x[2], x[3]);
+        row[1] = make_uint4(x[4], x[5], x[6], x[7]);
+        row[2] = make_uint4(x[8], x[9], x[10], x[11]);
     } else {
         out[epoch * kThreads + t] = v;
     }

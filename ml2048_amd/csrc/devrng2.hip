@@ -387,17 +387,19 @@ __global__ __launch_bounds__(256) void k2_rows(Layout l) {
 // ---- apply: every table row through all regenerations of the segment, epoch tables out.
 // Sixteen lanes per row: lane c holds the permutation of regeneration 16*chunk + c, an inclusive scan of
 // compositions over the sixteen lanes (four rounds) gives every epoch's row at once.
-// EXPANDED: epoch tables as 32-byte rows = the permutation + its inverse in board layout (what
-// ml2048_rollout_chain consumes, board_ops.hpp spawn_table_inv)
+// EXPANDED: epoch tables as 48-byte expanded rows (what ml2048_rollout_chain consumes, board_ops.hpp
+// expand_perm_row / spawn_table_dot)
 template <bool EXPANDED>
 __device__ __forceinline__ void store_epoch_row(uint8_t *perm_epochs, size_t epoch, uint32_t r, uint4 v) {
     uint4 *out = reinterpret_cast<uint4 *>(perm_epochs);
     if (EXPANDED) {
         const uint32_t perm[4] = {v.x, v.y, v.z, v.w};
-        uint32_t inv[4];
-        ml2048::invert_perm_row(perm, inv);
-        out[2 * (epoch * ML2048_RAND_SIZE + r)] = v;
-        out[2 * (epoch * ML2048_RAND_SIZE + r) + 1] = make_uint4(inv[0], inv[1], inv[2], inv[3]);
+        uint32_t x[ml2048::kExpandedRowWords];
+        ml2048::expand_perm_row(perm, x);
+        uint4 *row = out + 3 * (epoch * ML2048_RAND_SIZE + r);
+        row[0] = make_uint4(x[0], x[1], x[2], x[3]);
+        row[1] = make_uint4(x[4], x[5], x[6], x[7]);
+        row[2] = make_uint4(x[8], x[9], x[10], x[11]);
     } else {
         out[epoch * ML2048_RAND_SIZE + r] = v;
     }

@@ -882,8 +882,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
     int e1 = 0;
     int64_t rp1 = 0, rs1 = 0;             // schedule entry of step t + VPF
     uint32_t n_two_mask = 0, n_perm_p = 0; // VPF: data of step t, in flight since the previous iteration
-    uint32_t n_perm_s[4] = {0, 0, 0, 0}, n_inv_s[4] = {0, 0, 0, 0};
-    constexpr int64_t kEpochBytes = (int64_t)ML2048_RAND_SIZE * (INV ? 32 : 16);
+    uint32_t n_perm_s[4] = {0, 0, 0, 0}, n_wlo_s[4] = {0, 0, 0, 0}, n_whi_s[4] = {0, 0, 0, 0};
+    constexpr int64_t kEpochBytes = (int64_t)ML2048_RAND_SIZE * (INV ? 16 * kExpandedRowUnits : 16);
     // an epoch index is clamped to the tables that exist: a corrupted schedule then yields wrong
     // boards, never an out-of-bounds read (rows are already taken modulo the table size)
     const uint32_t e_last = (uint32_t)(n_epochs - 1);
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
             const uint8_t *tab0 = perm_epochs + (int64_t)e1 * kEpochBytes;
             n_two_mask = two_masks[e1];
             n_perm_p = load_table_head<INV>(tab0, rp1 + idx_base + ii);
-            load_table_row<INV>(tab0, rs1 + idx_base + ii, n_perm_s, n_inv_s);
+            load_table_row<INV>(tab0, rs1 + idx_base + ii, n_perm_s, n_wlo_s, n_whi_s);
             const int j1 = N > 1 ? 1 : 0;
             const uint32_t e1r = (uint32_t)schedule[3 * j1 + 0];
             e1 = (int)(e1r < e_last ? e1r : e_last);
@@ -952,7 +952,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                 uint32_t two_mask = n_two_mask;
                 uint32_t perm_p = n_perm_p;
                 uint32_t perm_s[4] = {n_perm_s[0], n_perm_s[1], n_perm_s[2], n_perm_s[3]};
-                uint32_t inv_s[4] = {n_inv_s[0], n_inv_s[1], n_inv_s[2], n_inv_s[3]};
+                uint32_t wlo_s[4] = {n_wlo_s[0], n_wlo_s[1], n_wlo_s[2], n_wlo_s[3]};
+                uint32_t whi_s[4] = {n_whi_s[0], n_whi_s[1], n_whi_s[2], n_whi_s[3]};
 #ifdef ML2048_LONE_WAVE
                 if (!FAST && VPF) {
                     // requests for step t+1 from the chunk's lane-held schedule (lane q = entry t0 + q + 1)
@@ -961,16 +962,20 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                     const uint32_t s_rp = (uint32_t)__builtin_amdgcn_readlane((int)sch_rp, q);
                     const uint32_t s_rs = (uint32_t)__builtin_amdgcn_readlane((int)sch_rs, q);
                     n_two_mask = (uint32_t)__builtin_amdgcn_readlane((int)sch_tm, q);
-                    constexpr uint32_t kRowBytes = INV ? 32u : 16u;
+                    constexpr uint32_t kRowBytes = INV ? 16u * kExpandedRowUnits : 16u;
                     const uint32_t off_p = ((s_rp + row_lane) & (uint32_t)(ML2048_RAND_SIZE - 1)) * kRowBytes + s_eo;
                     const uint32_t off_s = ((s_rs + row_lane) & (uint32_t)(ML2048_RAND_SIZE - 1)) * kRowBytes + s_eo;
                     n_perm_p = *reinterpret_cast<const uint32_t *>(perm_epochs + off_p);
                     const uint4 *row = reinterpret_cast<const uint4 *>(perm_epochs + off_s);
-                    const uint4 v = row[0];
-                    n_perm_s[0] = v.x; n_perm_s[1] = v.y; n_perm_s[2] = v.z; n_perm_s[3] = v.w;
                     if (INV) {
-                        const uint4 w = row[1];
-                        n_inv_s[0] = w.x; n_inv_s[1] = w.y; n_inv_s[2] = w.z; n_inv_s[3] = w.w;
+                        const uint2 p = *reinterpret_cast<const uint2 *>(row);
+                        const uint4 v = row[1], w = row[2];
+                        n_perm_s[0] = p.x; n_perm_s[1] = p.y;
+                        n_wlo_s[0] = v.x; n_wlo_s[1] = v.y; n_wlo_s[2] = v.z; n_wlo_s[3] = v.w;
+                        n_whi_s[0] = w.x; n_whi_s[1] = w.y; n_whi_s[2] = w.z; n_whi_s[3] = w.w;
+                    } else {
+                        const uint4 v = row[0];
+                        n_perm_s[0] = v.x; n_perm_s[1] = v.y; n_perm_s[2] = v.z; n_perm_s[3] = v.w;
                     }
                 } else
 #endif
@@ -979,11 +984,11 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                     if (VPF) { // requests for step t+1, consumed one iteration later
                         n_two_mask = two_masks[e1];
                         n_perm_p = load_table_head<INV>(tab1, rp1 + idx_base + ii);
-                        load_table_row<INV>(tab1, rs1 + idx_base + ii, n_perm_s, n_inv_s);
+                        load_table_row<INV>(tab1, rs1 + idx_base + ii, n_perm_s, n_wlo_s, n_whi_s);
                     } else {
                         two_mask = two_masks[e1];
                         perm_p = load_table_head<INV>(tab1, rp1 + idx_base + ii);
-                        load_table_row<INV>(tab1, rs1 + idx_base + ii, perm_s, inv_s);
+                        load_table_row<INV>(tab1, rs1 + idx_base + ii, perm_s, wlo_s, whi_s);
                     }
                     const int j2 = t + 1 + VPF < N ? t + 1 + VPF : N - 1;
                     const uint32_t e2r = (uint32_t)schedule[3 * j2 + 0];
@@ -1022,8 +1027,12 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                         spawn_word(s.board, w0, (uint32_t)thr);
                         spawn_word(s.board, w1, (uint32_t)thr);
                     } else {
-                        const uint32_t head[4] = {perm_p, 0, 0, 0};
-                        deal_table(s.board, head, two_mask);
+                        if (INV) {
+                            deal_table_nibbles(s.board, perm_p, two_mask);
+                        } else {
+                            const uint32_t head[4] = {perm_p, 0, 0, 0};
+                            deal_table(s.board, head, two_mask);
+                        }
                     }
                     if (!LAZY) s.valid = valid_actions(s.board);
                     if (DEFER) { // score 0 on the dealt board at step 0: its potential is 0
@@ -1062,7 +1071,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                     if (FAST) {
                         empties = spawn_word(s.board, sw[0], (uint32_t)thr);
                     } else {
-                        if (INV) empties = spawn_table_inv(s.board, perm_s, inv_s, two_mask);
+                        if (INV) empties = spawn_table_dot(s.board, perm_s[0], perm_s[1], wlo_s, whi_s, two_mask);
                         else spawn_table(s.board, perm_s, two_mask, 1);
                     }
                     if (LAZY && (FAST || INV)) step_post_lazy(s, empties);

@@ -880,7 +880,7 @@ class VecGame:
         """Enqueue the GPU computation of the next N-step draw schedule (csrc/devrng2.hip) and return
         device views (perm_epochs, schedule, two_masks, max_epochs).  The schedule kernels run on a
         side stream, one slot ahead is possible: the rollout stream only waits for its own slot.
-        expanded: epoch tables as 32-byte rows (permutation + inverse), for ml2048_rollout_chain."""
+        expanded: epoch tables as 48-byte expanded rows (ml2048_hip.h), for ml2048_rollout_chain."""
         L, dev = self._L, self.device
         if self._devrng_ws is None:
             # default: the data-parallel generation (csrc/devrng2.hip); ML2048_DEVRNG=1 selects the original
@@ -902,7 +902,7 @@ class VecGame:
             for _ in range(3):  # a ring of three: generation k+1 must not wait for the rollout that read slot k-1
                 # (with two, each cross-stream hand-over - about 20 us - sat on the critical path twice per period)
                 slots.append({
-                    "perm": torch.empty((cap, RAND_SIZE, 32), dtype=torch.uint8, device=dev),  # room for the expanded form
+                    "perm": torch.empty((cap, RAND_SIZE, 48), dtype=torch.uint8, device=dev),  # room for the expanded form
                     "sched": torch.empty((N, 3), dtype=torch.int32, device=dev),
                     "mask": torch.empty((cap,), dtype=torch.int32, device=dev),
                     "ne": torch.zeros((1,), dtype=torch.int32, device=dev),
@@ -985,8 +985,8 @@ class VecGame:
             asyn = self._schedule_mode == "host-async"
             plain = trajectory is None and not record_actions and not digests
             # The pipelined form (host-async, plain rollouts) keeps EXPANDED tables on the device: every
-            # 16-byte permutation row followed by its inverse (what the upload kernels produce), for the
-            # one-shift-per-cell spawn of ml2048_rollout_chain.  A schedule taken ahead for another length,
+            # 16-byte permutation row as 48 bytes of nibbles + dot-product weights (what the upload kernels
+            # produce), for the eight-instruction spawn of ml2048_rollout_chain.  A schedule taken ahead for another length,
             # or in front of a rollout with optional outputs (which reads the plain layout), is dropped with
             # the stream: the generator is re-synchronised to what was executed and the schedule redrawn.
             if asyn and self._la is not None and (self._la["N"] != N or not plain):
@@ -997,9 +997,9 @@ class VecGame:
             expand = asyn and plain
 
             def dev_layout(E, o_mask, o_tab, nbytes):
-                # device copy: [schedule | masks | tables], the tables with their inverse rows when expanded
+                # device copy: [schedule | masks | tables], the tables as 48-byte expanded rows when `expand`
                 return {"E": E, "o_mask": o_mask, "o_tab": o_tab, "host_nbytes": nbytes,
-                        "nbytes": nbytes + (nbytes - o_tab if expand else 0),
+                        "nbytes": nbytes + (2 * (nbytes - o_tab) if expand else 0),
                         "tab": o_tab if expand else nbytes, "inv": expand}
 
             with self._dev_ctx():
@@ -1075,7 +1075,7 @@ class VecGame:
                     self._fast_counter, self._reward_kind, int(masked), int(act_seed), int(act_counter),
                     a_ptr, d_ptr, flags.data_ptr(), last.data_ptr()), "rollout_fast")
                 self._fast_counter += N
-            elif on_device and dev_expanded:  # tables with inverse rows straight from the device schedule
+            elif on_device and dev_expanded:  # expanded tables straight from the device schedule
                 _lib.check(L.ml2048_rollout_chain(
                     self._stream(join=False), M, self._idx_base, self._st(), N, perm_dev.data_ptr(), mask_dev.data_ptr(),
                     E, sched_dev.data_ptr(), self._reward_kind, int(masked), int(act_seed), int(act_counter),

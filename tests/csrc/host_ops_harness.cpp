@@ -86,7 +86,25 @@ int64_t h_move_forms_check(const uint8_t *boards, int64_t n) {
     return bad;
 }
 
-// spawn from the inverse permutation == spawn probing the permutation in order; returns differences
+// stable compaction by position masks (compact_cells) == the six-step bubble it replaced, on n x 4 cell words
+int64_t h_compact_check(const uint32_t *words, int64_t n) {
+    int64_t bad = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t a = words[4 * i], b = words[4 * i + 1], c = words[4 * i + 2], d = words[4 * i + 3];
+        uint32_t p = a, q = b, r = c, t = d;
+        compact_cells(a, b, c, d);
+        pull_into_empty(p, q);
+        pull_into_empty(q, r);
+        pull_into_empty(r, t);
+        pull_into_empty(p, q);
+        pull_into_empty(q, r);
+        pull_into_empty(p, q);
+        if (a != p || b != q || c != r || d != t) ++bad;
+    }
+    return bad;
+}
+
+// spawn from the inverse permutation / by dot products == spawn probing the permutation in order; returns differences
 int64_t h_spawn_forms_check(const uint8_t *boards, const uint8_t *perms, const uint32_t *two_masks, int64_t n) {
     int64_t bad = 0;
     for (int64_t i = 0; i < n; ++i) {
@@ -102,9 +120,29 @@ int64_t h_spawn_forms_check(const uint8_t *boards, const uint8_t *perms, const u
         }
         bool had_empty = false;
         for (int c = 0; c < 16; ++c) had_empty |= ((b.r[c >> 2] >> (8 * (c & 3))) & 0xFF) == 0;
+        // ... and so is the expanded row of the upload kernels: nibble i = perm[i]; the weight of cell c = 2^inv[c],
+        // in the low vector when inv[c] < 8, in the high one (as 2^(inv[c]-8)) otherwise
+        uint32_t x[kExpandedRowWords];
+        expand_perm_row(perm, x);
+        if (x[2] != 0 || x[3] != 0) ++bad;
+        for (int k = 0; k < 16; ++k)
+            if (((x[k >> 3] >> (4 * (k & 7))) & 0xFu) != ((perm[k >> 2] >> (8 * (k & 3))) & 0xFFu)) ++bad;
+        for (int c = 0; c < 16; ++c) {
+            const uint32_t pos = (inv[c >> 2] >> (8 * (c & 3))) & 0xFF;
+            const uint32_t wl = (x[4 + (c >> 2)] >> (8 * (c & 3))) & 0xFF, wh = (x[8 + (c >> 2)] >> (8 * (c & 3))) & 0xFF;
+            if (wl != (pos < 8 ? 1u << pos : 0u) || wh != (pos >= 8 ? 1u << (pos - 8) : 0u)) ++bad;
+        }
+        Board d = a, e = a;
         spawn_table(a, perm, two_masks[i], 1);
         const uint32_t empties = spawn_table_inv(b, perm, inv, two_masks[i]);
         if (memcmp(a.r, b.r, 16) != 0) ++bad;
+        const uint32_t empties_dot = spawn_table_dot(d, x[0], x[1], x + 4, x + 8, two_masks[i]);
+        if (memcmp(a.r, d.r, 16) != 0 || empties_dot != empties) ++bad;
+        // the re-deal from the row's head, byte form and nibble form
+        deal_table(e, perm, two_masks[i]);
+        Board f;
+        deal_table_nibbles(f, x[0], two_masks[i]);
+        if (memcmp(e.r, f.r, 16) != 0) ++bad;
         if (had_empty) { // "terminated" from the spawn's emptiness mask == the full test on the board after the spawn
             StepRegs s1 = {}, s2 = {};
             s1.board = b, s2.board = b;

@@ -32,6 +32,8 @@ def H():
     L.h_transpose.argtypes = [vp, vp]
     L.h_spawn_forms_check.argtypes = [vp, vp, vp, i64]
     L.h_spawn_forms_check.restype = i64
+    L.h_compact_check.argtypes = [vp, i64]
+    L.h_compact_check.restype = i64
     L.h_move_forms_check.argtypes = [vp, i64]
     L.h_move_forms_check.restype = i64
     L.h_lazy_mask_check.argtypes = [vp, i64]
@@ -201,9 +203,24 @@ def test_move_all_lines_at_once_equals_line_by_line(H):
     assert H.h_move_forms_check(_p(allb), allb.shape[0]) == 0
 
 
+def test_compaction_by_position_masks_equals_the_bubble(H):
+    """compact_cells (every cell OR-ed into the position it lands on) against six pull_into_empty steps: all 18^4
+    lines in every byte lane, and random cell words with many zeros."""
+    rng = np.random.default_rng(4)
+    lines = np.array(list(np.ndindex(18, 18, 18, 18)), dtype=np.uint8)              # (104976, 4): cells a, b, c, d
+    words = np.zeros((lines.shape[0], 4, 4), np.uint8)                              # [case][cell word][byte lane]
+    for lane in range(4):
+        words[:, :, lane] = np.roll(lines, lane * 1009, axis=0)                     # different lines side by side
+    rnd = rng.integers(0, 18, size=(300000, 4, 4)).astype(np.uint8)
+    rnd[rng.random(rnd.shape) < 0.5] = 0
+    allw = np.ascontiguousarray(np.concatenate([words, rnd]).reshape(-1, 16)).view(np.uint32)
+    assert H.h_compact_check(_p(allw), allw.shape[0]) == 0
+
+
 def test_spawn_from_inverse_permutation_equals_probing_spawn(H):
-    """spawn_table_inv (one SDWA shift per cell + OR tree on the row's inverse permutation) places the
-    same tile as spawn_table for random boards (sparse, dense, full, empty) and random permutations."""
+    """spawn_table_inv (one SDWA shift per cell + OR tree on the row's inverse permutation) and spawn_table_dot (dot
+    products with the expanded row's weights - what the plain fused rollout runs) place the same tile as spawn_table
+    for random boards (sparse, dense, full, empty) and random permutations; the expanded row is checked field by field."""
     rng = np.random.default_rng(21)
     n = 200000
     boards = _random_boards(rng, n)
