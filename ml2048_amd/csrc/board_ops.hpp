@@ -517,12 +517,19 @@ ML_HD uint32_t spawn_table_dot(Board &b, uint32_t pn_lo, uint32_t pn_hi, const u
     return hits;
 }
 
-// the re-deal from the head of an expanded row (nibbles 0 and 1 of pn_lo)
+// the re-deal from the head of an expanded row (nibbles 0 and 1 of pn_lo): each tile is shifted into place inside
+// its half of the board as a 64-bit value (two v_lshlrev_b64 and four selects instead of two set_cell chains - the deal
+// runs in ~40 % of a wave's steps, whenever one of its 64 games has ended)
 ML_HD void deal_table_nibbles(Board &b, uint32_t pn_lo, uint32_t two_mask) {
     const uint32_t c1 = pn_lo & 0xFu, c2 = (pn_lo >> 4) & 0xFu;
-    b.r[0] = b.r[1] = b.r[2] = b.r[3] = 0;
-    set_cell(b, c1, 2u - ubfe(two_mask, c1, 1));
-    set_cell(b, c2, 2u - ubfe(two_mask, c2, 1));
+    const uint64_t t1 = (uint64_t)(2u - ubfe(two_mask, c1, 1)) << (8u * (c1 & 7u));
+    const uint64_t t2 = (uint64_t)(2u - ubfe(two_mask, c2, 1)) << (8u * (c2 & 7u));
+    const uint64_t lo = ((c1 & 8u) ? 0ull : t1) | ((c2 & 8u) ? 0ull : t2);
+    const uint64_t hi = ((c1 & 8u) ? t1 : 0ull) | ((c2 & 8u) ? t2 : 0ull);
+    b.r[0] = (uint32_t)lo;
+    b.r[1] = (uint32_t)(lo >> 32);
+    b.r[2] = (uint32_t)hi;
+    b.r[3] = (uint32_t)(hi >> 32);
 }
 
 // the two tiles of a freshly dealt (empty) board: the first two entries of the permutation row
