@@ -927,8 +927,16 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
     auto run_steps = [&](auto lazy_tag, auto defer_tag) {
         constexpr bool LAZY = decltype(lazy_tag)::value;
         constexpr bool DEFER = decltype(defer_tag)::value; // no reward arithmetic in the loop (always with LAZY)
-        for (int t0 = 0; t0 < N; t0 += kFlagChunk) {
-            const int t1 = t0 + kFlagChunk < N ? t0 + kFlagChunk : N;
+        // LAZY (always two bits per draw, sixteen draws per word): the first chunk is cut short so that every later
+        // group of kStepUnroll steps starts on a multiple of kStepUnroll of the sampler's counter - a new word can then
+        // only fall due at the first step of a group, and the other steps carry no test for it (a wave-uniform branch
+        // per step that was taken fifteen times out of sixteen: with one wave per SIMD every taken branch is an
+        // instruction-buffer refill nobody hides).
+        constexpr bool WORD_AT_GROUP_START = LAZY && kStepUnroll > 1 && 16 % kStepUnroll == 0;
+        const int first_len = WORD_AT_GROUP_START ? (int)((0 - act_counter0) & (uint64_t)(kStepUnroll - 1)) : 0;
+        for (int t0 = 0, t1 = 0; t0 < N; t0 = t1) {
+            const int len = (t0 == 0 && first_len > 0) ? first_len : kFlagChunk;
+            t1 = t0 + len < N ? t0 + len : N;
 #ifdef ML2048_LONE_WAVE
             // The schedule of this chunk, one entry per lane (lane q: the entry step t0 + q fetches ahead, i.e.
             // step t0 + q + 1's): epoch as a byte offset into the tables, the two row bases, the epoch's two-mask.
@@ -946,7 +954,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                 sch_tm = two_masks[ec];
             }
 #endif
-            auto one_step = [&](const int t) __attribute__((always_inline)) {
+            auto one_step = [&](const int t, auto word_check_tag) __attribute__((always_inline)) {
+                constexpr bool WORD_CHECK = decltype(word_check_tag)::value; // may this step be the first of a sampler word
                 // table mode: the pre-drawn host schedule; fast mode: rocRAND Philox words keyed
                 // (spawn_seed; board; 2*(counter0+t) for the deal, +1 for the step) as the per-step API does
                 uint32_t two_mask = n_two_mask;
@@ -1045,7 +1054,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                 const uint64_t tt = act_counter0 + (uint64_t)t;
                 const bool plain = LAZY || !masked; // two bits per draw; LAZY instantiations are never masked
                 const uint32_t sub = plain ? (uint32_t)(tt & 15ull) : 0u;
-                if (t > 0 && sub == 0) { // wave-uniform: the next word of the stream
+                if (WORD_CHECK && t > 0 && sub == 0) { // wave-uniform: the next word of the stream
                     const uint64_t j = plain ? (tt >> 4) : tt;
                     if ((j & 3ull) == 0) {
                         rocrand_state_philox4x32_10 rs;
@@ -1138,11 +1147,12 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
             int t = t0;
             if constexpr (U > 1) {
                 for (; t + U <= t1; t += U) {
+                    one_step(t, std::true_type{});
 #pragma unroll
-                    for (int u = 0; u < U; ++u) one_step(t + u);
+                    for (int u = 1; u < U; ++u) one_step(t + u, std::bool_constant<!WORD_AT_GROUP_START>{});
                 }
             }
-            for (; t < t1; ++t) one_step(t);
+            for (; t < t1; ++t) one_step(t, std::true_type{});
 #ifdef ML2048_LONE_WAVE
             // flush this chunk's re-deal flags: lane q holds step t0 + q
             if (lane < t1 - t0)
