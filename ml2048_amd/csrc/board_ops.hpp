@@ -489,6 +489,11 @@ ML_HD void expand_perm_row(const uint32_t perm[4], uint32_t out[kExpandedRowWord
 
 // one tile (the step's spawn); equals spawn_table(b, perm, two_mask, 1) when the row is expand_perm_row(perm).
 // Returns the emptiness mask before the spawn (bit i <=> the cell at position i of the row was empty).
+// HAS_EMPTY: the caller knows that the board has an empty cell - it always has after a move that changed it (a slide
+// keeps the number of empty cells, a merge adds one), which is the lazy loop's validity test; a caller that trusts a
+// stored valid-action mask instead (which load_records lets a user make inconsistent) must pass false, and a full
+// board is then left alone as _spawn2 leaves it.
+template <bool HAS_EMPTY = false>
 ML_HD uint32_t spawn_table_dot(Board &b, uint32_t pn_lo, uint32_t pn_hi, const uint32_t wlo[4], const uint32_t whi[4],
                                uint32_t two_mask) {
     uint32_t lo = 0, hi = 0;
@@ -501,12 +506,13 @@ ML_HD uint32_t spawn_table_dot(Board &b, uint32_t pn_lo, uint32_t pn_hi, const u
     const uint32_t hits = ((hi << 8) | lo) >> 7;
     // a full board (hits == 0: cannot follow a valid move) is left alone: a zero tile is OR-ed in (see spawn_table_inv)
 #ifndef ML2048_LONE_WAVE
-    if (hits == 0) return 0u;
+    if (!HAS_EMPTY && hits == 0) return 0u;
 #endif
-    const uint32_t i = hits ? (uint32_t)__builtin_ctz(hits) : 0u;
-    const uint64_t pn = (uint64_t)pn_lo | ((uint64_t)pn_hi << 32);
-    const uint32_t c = (uint32_t)(pn >> (4u * i)) & 0xFu;
-    const uint32_t val = hits ? 2u - ubfe(two_mask, c, 1) : 0u;
+    const bool some = HAS_EMPTY || hits != 0u;
+    const uint32_t i = some ? (uint32_t)__builtin_ctz(hits) : 0u;
+    // nibble i of the permutation (32-bit forms: the 64-bit shifts are multi-pass instructions)
+    const uint32_t c = ubfe((i & 8u) ? pn_hi : pn_lo, 4u * i, 4); // v_bfe_u32 takes the offset modulo 32
+    const uint32_t val = some ? 2u - ubfe(two_mask, c, 1) : 0u;
     const uint64_t t = (uint64_t)val << (8u * (c & 7u)); // the tile in its half of the board
     const bool upper = (c & 8u) != 0u;
     const uint32_t tl = (uint32_t)t, th = (uint32_t)(t >> 32);

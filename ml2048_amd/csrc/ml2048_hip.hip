@@ -927,16 +927,15 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
     auto run_steps = [&](auto lazy_tag, auto defer_tag) {
         constexpr bool LAZY = decltype(lazy_tag)::value;
         constexpr bool DEFER = decltype(defer_tag)::value; // no reward arithmetic in the loop (always with LAZY)
-        // LAZY (always two bits per draw, sixteen draws per word): the first chunk is cut short so that every later
-        // group of kStepUnroll steps starts on a multiple of kStepUnroll of the sampler's counter - a new word can then
-        // only fall due at the first step of a group, and the other steps carry no test for it (a wave-uniform branch
-        // per step that was taken fifteen times out of sixteen: with one wave per SIMD every taken branch is an
-        // instruction-buffer refill nobody hides).
-        constexpr bool WORD_AT_GROUP_START = LAZY && kStepUnroll > 1 && 16 % kStepUnroll == 0;
-        const int first_len = WORD_AT_GROUP_START ? (int)((0 - act_counter0) & (uint64_t)(kStepUnroll - 1)) : 0;
-        for (int t0 = 0, t1 = 0; t0 < N; t0 = t1) {
-            const int len = (t0 == 0 && first_len > 0) ? first_len : kFlagChunk;
-            t1 = t0 + len < N ? t0 + len : N;
+        // LAZY (always two bits per draw, sixteen draws per word): inside a chunk the groups of kStepUnroll steps start on
+        // a multiple of kStepUnroll of the sampler's counter (`group_lead` single steps come first; the chunks themselves
+        // start on multiples of kFlagChunk) - a new word can then only fall due at the first step of a group, and the
+        // other steps carry no test for it (a wave-uniform branch per step that was taken fifteen times out of sixteen:
+        // with one wave per SIMD every taken branch is an instruction-buffer refill nobody hides).
+        constexpr bool WORD_AT_GROUP_START = LAZY && kStepUnroll > 1 && 16 % kStepUnroll == 0 && kFlagChunk % kStepUnroll == 0;
+        const int group_lead = WORD_AT_GROUP_START ? (int)((0 - act_counter0) & (uint64_t)(kStepUnroll - 1)) : 0;
+        for (int t0 = 0; t0 < N; t0 += kFlagChunk) {
+            const int t1 = t0 + kFlagChunk < N ? t0 + kFlagChunk : N;
 #ifdef ML2048_LONE_WAVE
             // The schedule of this chunk, one entry per lane (lane q: the entry step t0 + q fetches ahead, i.e.
             // step t0 + q + 1's): epoch as a byte offset into the tables, the two row bases, the epoch's two-mask.
@@ -1080,7 +1079,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                     if (FAST) {
                         empties = spawn_word(s.board, sw[0], (uint32_t)thr);
                     } else {
-                        if (INV) empties = spawn_table_dot(s.board, perm_s[0], perm_s[1], wlo_s, whi_s, two_mask);
+                        if (INV) empties = spawn_table_dot<LAZY>(s.board, perm_s[0], perm_s[1], wlo_s, whi_s, two_mask);
                         else spawn_table(s.board, perm_s, two_mask, 1);
                     }
                     if (LAZY && (FAST || INV)) step_post_lazy(s, empties);
@@ -1145,11 +1144,20 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
             // unroll this loop by itself: it contains convergent operations and has a run-time trip count)
             constexpr int U = EXTRAS ? 1 : kStepUnroll;
             int t = t0;
+            if constexpr (WORD_AT_GROUP_START) {
+                const int lead_end = t0 + group_lead < t1 ? t0 + group_lead : t1;
+                for (; t < lead_end; ++t) one_step(t, std::true_type{});
+            }
             if constexpr (U > 1) {
                 for (; t + U <= t1; t += U) {
-                    one_step(t, std::true_type{});
+                    if constexpr (WORD_AT_GROUP_START) {
+                        one_step(t, std::true_type{});
 #pragma unroll
-                    for (int u = 1; u < U; ++u) one_step(t + u, std::bool_constant<!WORD_AT_GROUP_START>{});
+                        for (int u = 1; u < U; ++u) one_step(t + u, std::false_type{});
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) one_step(t + u, std::true_type{});
+                    }
                 }
             }
             for (; t < t1; ++t) one_step(t, std::true_type{});

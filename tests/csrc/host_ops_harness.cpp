@@ -132,7 +132,7 @@ int64_t h_spawn_forms_check(const uint8_t *boards, const uint8_t *perms, const u
             const uint32_t wl = (x[4 + (c >> 2)] >> (8 * (c & 3))) & 0xFF, wh = (x[8 + (c >> 2)] >> (8 * (c & 3))) & 0xFF;
             if (wl != (pos < 8 ? 1u << pos : 0u) || wh != (pos >= 8 ? 1u << (pos - 8) : 0u)) ++bad;
         }
-        Board d = a, e = a;
+        Board d = a, e = a, g = a;
         spawn_table(a, perm, two_masks[i], 1);
         const uint32_t empties = spawn_table_inv(b, perm, inv, two_masks[i]);
         if (memcmp(a.r, b.r, 16) != 0) ++bad;
@@ -143,6 +143,10 @@ int64_t h_spawn_forms_check(const uint8_t *boards, const uint8_t *perms, const u
         Board f;
         deal_table_nibbles(f, x[0], two_masks[i]);
         if (memcmp(e.r, f.r, 16) != 0) ++bad;
+        if (had_empty) { // the form for callers that know of an empty cell (the lazy loop, after a move that changed the board)
+            const uint32_t e2 = spawn_table_dot<true>(g, x[0], x[1], x + 4, x + 8, two_masks[i]);
+            if (memcmp(a.r, g.r, 16) != 0 || e2 != empties) ++bad;
+        }
         if (had_empty) { // "terminated" from the spawn's emptiness mask == the full test on the board after the spawn
             StepRegs s1 = {}, s2 = {};
             s1.board = b, s2.board = b;
