@@ -348,6 +348,30 @@ int ml2048_rollout_chain(void *stream, int64_t M, int64_t idx_base, const ml2048
                          int64_t next_table_offset);
 
 /*
+ * Host-side plumbing of the pipelined rollout.  Events are hipEvent_t handles (timing disabled) created by the library
+ * so that a binding can record / wait / poll them without its framework's event objects:
+ *   query: 1 = everything recorded into the event has finished (or nothing ever was), 0 = pending, < 0 error.
+ * ml2048_rollout_chain_ids = ml2048_rollout_chain on `stream`, then rollout_event (may be NULL) recorded behind its
+ * kernel, then - when scratch != NULL - ml2048_rollout_finish_ids on ids_stream (== stream: inline; another stream:
+ * it first waits for rollout_event, so the scan runs beside whatever `stream` does next) and ids_done_event (may be
+ * NULL) recorded behind the scan.  One call instead of five: the host side of a 70 us kernel has to stay well below it.
+ * (No counterpart in the reference, whose loop is synchronous Python, runner.py:74-117.)
+ */
+int ml2048_event_create(void **event);
+void ml2048_event_destroy(void *event);
+int ml2048_event_record(void *event, void *stream);
+int ml2048_event_query(void *event);
+int ml2048_event_synchronize(void *event);
+int ml2048_stream_wait_event(void *stream, void *event);
+int ml2048_rollout_chain_ids(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
+                             const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,
+                             const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed,
+                             uint64_t act_counter0, uint64_t *reset_flags, int32_t *last_reset,
+                             const void *next_src_host, void *next_dst, int64_t next_nbytes, int64_t next_table_offset,
+                             void *rollout_event, void *ids_stream, int32_t *game_count, int32_t *step_resets,
+                             int32_t *scratch, void *ids_done_event);
+
+/*
  * Upload of a pre-drawn schedule: a copy KERNEL that reads device-accessible (pinned / registered)
  * host memory directly, so that the upload is an ordinary launch on `stream` and involves neither the
  * copy engine nor a host wait.  dst: device, src_host: pinned host memory, both 16-byte aligned; nbytes

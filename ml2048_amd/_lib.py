@@ -131,6 +131,12 @@ _SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ml2048_episode_stats": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(State), C.c_void_p, C.c_void_p, C.c_int32,
                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ml2048_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "ml2048_event_destroy": (None, [C.c_void_p]),
+    "ml2048_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ml2048_event_query": (C.c_int, [C.c_void_p]),
+    "ml2048_event_synchronize": (C.c_int, [C.c_void_p]),
+    "ml2048_stream_wait_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ml2048_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
     "ml2048_rollout": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_int32, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
@@ -138,6 +144,10 @@ _SIGNATURES = {
     "ml2048_rollout_chain": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_int32, C.c_void_p,
                                        C.c_void_p, C.c_int32, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
+    "ml2048_rollout_chain_ids": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_int32, C.c_void_p,
+                                           C.c_void_p, C.c_int32, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ml2048_rollout_traj": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_int32, C.c_void_p,
                                       C.c_void_p, C.c_int32, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                       C.c_void_p, C.c_void_p, C.POINTER(Traj)]),

@@ -391,6 +391,8 @@ ML_HD void spawn_table(Board &b, const uint32_t perm[4], uint32_t two_mask, int 
 }
 
 // ---- the same spawn from the row's INVERSE permutation ------------------------------------------
+// (round 1's form of the plain rollout's spawn; the kernels now use spawn_table_dot below, and this one stays as the
+// intermediate step of the host cross-check: probing == inverse-shift == dot products, tests/test_host_ops.py)
 // inv[c] = position of cell c in the permutation row, laid out like the board (byte j of word k =
 // cell 4k+j).  Then  hits = OR over empty cells c of (1 << inv[c])  needs no per-position probing: one
 // SDWA shift per cell - byte j of the emptiness flags (0x80 / 0) shifted left by byte j of inv - and

@@ -1936,6 +1936,76 @@ int ml2048_rollout_finish_ids(void *stream, int64_t M, const ml2048_state *st, i
     return check_launch("ml2048_rollout_finish_ids");
 }
 
+// ---- events of the pipelined rollout (host-side plumbing: every call below is one HIP runtime call) ----------------
+int ml2048_event_create(void **event) {
+    if (!event) return fail(ML2048_E_INVALID, "event is NULL");
+    hipEvent_t e;
+    const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (rc != hipSuccess) return fail((int)rc, "hipEventCreateWithFlags: %s", hipGetErrorString(rc));
+    *event = (void *)e;
+    return 0;
+}
+
+void ml2048_event_destroy(void *event) {
+    if (event) (void)hipEventDestroy((hipEvent_t)event);
+}
+
+int ml2048_event_record(void *event, void *stream) {
+    if (!event) return fail(ML2048_E_INVALID, "event is NULL");
+    const hipError_t rc = hipEventRecord((hipEvent_t)event, (hipStream_t)stream);
+    return rc == hipSuccess ? 0 : fail((int)rc, "hipEventRecord: %s", hipGetErrorString(rc));
+}
+
+// 1 = everything recorded into the event has finished (or nothing ever was), 0 = still pending
+int ml2048_event_query(void *event) {
+    if (!event) return fail(ML2048_E_INVALID, "event is NULL");
+    const hipError_t rc = hipEventQuery((hipEvent_t)event);
+    if (rc == hipSuccess) return 1;
+    if (rc == hipErrorNotReady) {
+        (void)hipGetLastError(); // "not ready" is an answer, not an error to leave behind
+        return 0;
+    }
+    return fail(ML2048_E_INVALID, "hipEventQuery: %s", hipGetErrorString(rc));
+}
+
+int ml2048_event_synchronize(void *event) {
+    if (!event) return fail(ML2048_E_INVALID, "event is NULL");
+    const hipError_t rc = hipEventSynchronize((hipEvent_t)event);
+    return rc == hipSuccess ? 0 : fail((int)rc, "hipEventSynchronize: %s", hipGetErrorString(rc));
+}
+
+int ml2048_stream_wait_event(void *stream, void *event) {
+    if (!event) return fail(ML2048_E_INVALID, "event is NULL");
+    const hipError_t rc = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0);
+    return rc == hipSuccess ? 0 : fail((int)rc, "hipStreamWaitEvent: %s", hipGetErrorString(rc));
+}
+
+// ml2048_rollout_chain + the marker behind its kernel + ml2048_rollout_finish_ids (on the same or on a side stream) in
+// ONE call: what VecGame.rollout() issues per plain rollout, without a Python round trip per piece
+int ml2048_rollout_chain_ids(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
+                             const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,
+                             const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0,
+                             uint64_t *reset_flags, int32_t *last_reset, const void *next_src_host, void *next_dst,
+                             int64_t next_nbytes, int64_t next_table_offset, void *rollout_event, void *ids_stream,
+                             int32_t *game_count, int32_t *step_resets, int32_t *scratch, void *ids_done_event) {
+    const bool ids = scratch != nullptr;
+    if (ids && ids_stream != stream && !rollout_event)
+        return fail(ML2048_E_INVALID, "an id scan on another stream needs rollout_event to wait for");
+    if (ids && !game_count) return fail(ML2048_E_INVALID, "game_count is NULL");
+    if (int rc = ml2048_rollout_chain(stream, M, idx_base, st, N, perm_epochs, two_masks, n_epochs, schedule, reward_kind, masked,
+                                      act_seed, act_counter0, reset_flags, last_reset, next_src_host, next_dst, next_nbytes,
+                                      next_table_offset))
+        return rc;
+    if (rollout_event)
+        if (int rc = ml2048_event_record(rollout_event, stream)) return rc;
+    if (!ids) return 0;
+    if (ids_stream != stream)
+        if (int rc = ml2048_stream_wait_event(ids_stream, rollout_event)) return rc;
+    if (int rc = ml2048_rollout_finish_ids(ids_stream, M, st, N, reset_flags, last_reset, game_count, step_resets, scratch)) return rc;
+    if (ids_done_event) return ml2048_event_record(ids_done_event, ids_stream);
+    return 0;
+}
+
 int ml2048_episode_stats(void *stream, int64_t M, const ml2048_state *st, int32_t *age, int32_t *seen_id,
                          int32_t id_base, int32_t rounds, uint64_t *count, uint64_t *step_sum, uint64_t *score_sum) {
     if (int rc = check_state(M, st)) return rc;

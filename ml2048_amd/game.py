@@ -16,6 +16,7 @@ Differences from the reference, all deliberate and documented in DESIGN.md:
 from __future__ import annotations
 
 import collections
+import collections.abc
 import ctypes as C
 import os
 from typing import Any, Optional, TypedDict
@@ -143,6 +144,68 @@ _NULL_CTX = _NullCtx()
 _NO_NEXT = (None, None)
 
 
+class _Event:
+    """A hipEvent_t of the library (ml2048_event_*): record / query / synchronize / wait without torch's event objects -
+    a plain rollout issues one ctypes call for the launch, its marker and the id scan (ml2048_rollout_chain_ids), and
+    only these handles cross the boundary."""
+    __slots__ = ("h", "_L")
+
+    def __init__(self, L):
+        h = C.c_void_p()
+        _lib.check(L.ml2048_event_create(C.byref(h)), "event_create")
+        self.h, self._L = h.value, L
+
+    def record(self, stream_raw: int) -> None:
+        _lib.check(self._L.ml2048_event_record(self.h, stream_raw), "event_record")
+
+    def query(self) -> bool:
+        r = self._L.ml2048_event_query(self.h)
+        if r < 0:
+            _lib.check(r, "event_query")
+        return r == 1
+
+    def synchronize(self) -> None:
+        _lib.check(self._L.ml2048_event_synchronize(self.h), "event_synchronize")
+
+    def __del__(self):
+        try:
+            self._L.ml2048_event_destroy(self.h)
+        except Exception:
+            pass
+
+
+class _RolloutBuffers(collections.abc.Mapping):
+    """What a plain rollout returns: the same keys as the dict of the general path, over ONE device allocation whose
+    views are only built when somebody asks for them (a view costs more host time than the rollout has to spare)."""
+    _KEYS = ("actions", "digests", "step_resets", "reset_flags", "last_reset")
+
+    def __init__(self, buf, N, W, M, o_last, o_resets, has_resets):
+        self._buf, self._dims, self._views = buf, (N, W, M, o_last, o_resets, has_resets), {}
+
+    def __getitem__(self, key):
+        if key not in self._KEYS:
+            raise KeyError(key)
+        if key not in self._views:
+            N, W, M, o_last, o_resets, has_resets = self._dims
+            b = self._buf
+            if key == "reset_flags":
+                v = b[:N * W * 8].view(torch.int64).view(N, W)
+            elif key == "last_reset":
+                v = b[o_last:o_last + M * 4].view(torch.int32)
+            elif key == "step_resets":
+                v = b[o_resets:o_resets + N * 4].view(torch.int32) if has_resets else None
+            else:
+                v = None
+            self._views[key] = v
+        return self._views[key]
+
+    def __iter__(self):
+        return iter(self._KEYS)
+
+    def __len__(self):
+        return len(self._KEYS)
+
+
 class VecGame:
     """Vectorized 2048 environment on one MI355X (see module docstring)."""
 
@@ -196,6 +259,7 @@ class VecGame:
         self._spin = [None, None, None, None]  # pinned staging ring: [tensor, event of the launch that reads it]
         self._spin_i = 0
         self._roll_ev = None        # ring of per-rollout events (ONE record per rollout, after its kernel)
+        self._plain_layouts = {}    # (M, N) -> offsets inside a plain rollout's one device allocation
         self._roll_i = 0
         self._sdev = [None, None]   # device-side packed schedules (the resident one and the next one)
         self._sdev_i = 0
@@ -248,12 +312,72 @@ class VecGame:
         self.reset()  # :584 (unseeded, as the reference constructor does)
 
     # ------------------------------------------------------------------------------------------
+    def _next_roll_event(self) -> "_Event":
+        """The marker of the next rollout, from a ring longer than any ring / slot count that refers to its entries."""
+        if self._roll_ev is None:
+            self._roll_ev = [_Event(self._L) for _ in range(16)]
+        ev = self._roll_ev[self._roll_i]
+        self._roll_i = (self._roll_i + 1) % len(self._roll_ev)
+        return ev
+
+    def _ids_side_stream(self):
+        if self._ids_stream is None:
+            self._ids_stream = torch.cuda.Stream(device=self.device)
+            self._ids_done = _Event(self._L)
+        return self._ids_stream
+
+    def _rollout_plain_chain(self, N, masked, act_seed, act_counter, finish_ids, kernel_timer, packed_ptr, o_mask, o_tab,
+                             E, chain, staged):
+        """The pipelined plain rollout (schedule="host-async", no optional outputs): ONE native call launches the kernel
+        with the next schedule's upload chained to it, records its marker and issues the id scan
+        (ml2048_rollout_chain_ids); ONE device allocation holds the re-deal flags, the last-deal steps, the per-step
+        re-deal counts and the scan's scratch.  Everything here is on the critical path of a 70 us kernel."""
+        L, M, dev = self._L, self._size, self.device
+        key = (M, N)
+        lay = self._plain_layouts.get(key)
+        if lay is None:
+            W = int(L.ml2048_rollout_flag_words(M))
+            r16 = lambda x: (x + 15) // 16 * 16
+            o_last = r16(N * W * 8)
+            o_resets = o_last + r16(M * 4)
+            o_scratch = o_resets + r16(N * 4)
+            total = o_scratch + r16(int(L.ml2048_rollout_scratch_ints(M, N)) * 4)
+            lay = self._plain_layouts[key] = (W, o_last, o_resets, o_scratch, total)
+        W, o_last, o_resets, o_scratch, total = lay
+        with self._dev_ctx():
+            buf = torch.empty((total,), dtype=torch.uint8, device=dev)
+            base = buf.data_ptr()
+            main = self._raw_stream()
+            roll_ev = self._next_roll_event()
+            ids_stream, done, scratch = main, None, base + o_scratch
+            if finish_ids == "deferred":
+                # the rollout kernel reads neither ids nor the game counter, so the id scan of this rollout may run
+                # beside the NEXT rollout's kernel: a side stream, in order with the previous scans, joined by
+                # whatever touches ids next (join_ids)
+                side = self._ids_side_stream()
+                buf.record_stream(side)  # allocated on the launch stream, used on `side`
+                ids_stream, done = side.cuda_stream, self._ids_done.h
+            elif not finish_ids:
+                scratch = None
+            if kernel_timer is not None:
+                _lib.check(L.ml2048_timer_arm(kernel_timer), "timer_arm")
+            _lib.check(L.ml2048_rollout_chain_ids(
+                main, M, self._idx_base, self._st(), N, packed_ptr + o_tab, packed_ptr + o_mask, E, packed_ptr,
+                self._reward_kind, int(masked), int(act_seed), int(act_counter), base, base + o_last,
+                chain[0][0].data_ptr(), chain[1].data_ptr(), chain[2], chain[3], roll_ev.h, ids_stream,
+                self._game_count_dev.data_ptr(), base + o_resets, scratch, done), "rollout_chain_ids")
+        for ps in staged:  # the pinned slots this launch read: free once its marker has passed
+            ps[1] = roll_ev
+        if finish_ids == "deferred":
+            self._ids_pending = True
+        return _RolloutBuffers(buf, N, W, M, o_last, o_resets, bool(finish_ids))
+
     def join_ids(self) -> None:
         """Order the launch stream after a deferred id scan (`rollout(finish_ids="deferred")`).  Every
         method of this class does it implicitly; call it before reading a deferred rollout's
         `step_resets` with your own torch code."""
         if self._ids_pending:
-            torch.cuda.current_stream(self.device).wait_event(self._ids_done)
+            _lib.check(self._L.ml2048_stream_wait_event(self._raw_stream(), self._ids_done.h), "stream_wait_event")
             self._ids_pending = False
 
     @property
@@ -261,6 +385,12 @@ class VecGame:
         """(M,) int32 device tensor of game ids (the record's `id`, game_numba.py:641-644)."""
         self.join_ids()
         return self._game_id
+
+    def _raw_stream(self) -> int:
+        try:
+            return torch._C._cuda_getCurrentRawStream(self.device.index)
+        except AttributeError:  # pragma: no cover
+            return torch.cuda.current_stream(self.device).cuda_stream
 
     def _stream(self, join: bool = True) -> int:
         """hipStream_t of torch's current stream on this device (raw accessor: ~0.3 us vs ~4 us).
@@ -1033,11 +1163,14 @@ class VecGame:
                     self._la = nxt
             if asyn:
                 self._sstream_after = cur["after"]  # what _close_sched_stream re-synchronises the generator to
+            if E > 1:
+                self._tables_dirty = True  # device copies of the tables are refreshed lazily (per-step API)
+            if chain is not None and kernel_events is None:
+                return self._rollout_plain_chain(N, masked, act_seed, act_counter, finish_ids, kernel_timer,
+                                                 packed_dev.data_ptr(), o_mask, o_tab, E, chain, staged)
             perm_dev = packed_dev[o_tab:cur["nbytes"]]
             sched_dev = packed_dev[:N * 12]
             mask_dev = packed_dev[o_mask:o_mask + E * 4]
-            if E > 1:
-                self._tables_dirty = True  # device copies of the tables are refreshed lazily (per-step API)
 
         W = int(L.ml2048_rollout_flag_words(M))
         flags = torch.empty((N, W), dtype=torch.int64, device=dev)
@@ -1101,11 +1234,8 @@ class VecGame:
             if (not fast and not on_device and staged) or finish_ids == "deferred":
                 # ONE marker per rollout, right after its kernel: it frees the pinned buffers the launch
                 # read and is what a deferred id scan waits for (every marker costs GPU time between kernels)
-                if self._roll_ev is None:
-                    self._roll_ev = [torch.cuda.Event() for _ in range(16)]  # more than any ring / slot count that refers to them
-                roll_ev = self._roll_ev[self._roll_i]
-                self._roll_i = (self._roll_i + 1) % len(self._roll_ev)
-                roll_ev.record(torch.cuda.current_stream(dev))
+                roll_ev = self._next_roll_event()
+                roll_ev.record(self._raw_stream())
                 if not fast and not on_device:
                     for ps in staged:
                         ps[1] = roll_ev
@@ -1118,11 +1248,8 @@ class VecGame:
                     # rollout may run beside the NEXT rollout's kernel: a side stream, in order with the
                     # previous scans, joined by whatever touches ids next (join_ids)
                     main = torch.cuda.current_stream(dev)
-                    if self._ids_stream is None:
-                        self._ids_stream = torch.cuda.Stream(device=dev)
-                        self._ids_done = torch.cuda.Event()
-                    side = self._ids_stream
-                    side.wait_event(roll_ev)
+                    side = self._ids_side_stream()
+                    _lib.check(L.ml2048_stream_wait_event(side.cuda_stream, roll_ev.h), "stream_wait_event")
                     for buf in (flags, last, step_resets, scratch):  # allocated on `main`, used on `side`
                         buf.record_stream(side)
                     ids_stream = side.cuda_stream
@@ -1132,7 +1259,7 @@ class VecGame:
                     ids_stream, M, self._st(), N, flags.data_ptr(), last.data_ptr(),
                     self._game_count_dev.data_ptr(), step_resets.data_ptr(), scratch.data_ptr()), "rollout_finish_ids")
                 if finish_ids == "deferred":
-                    self._ids_done.record(side)
+                    self._ids_done.record(side.cuda_stream)
                     self._ids_pending = True
         # every temporary above was allocated on the launch stream, so the caching allocator's
         # stream-ordered reuse keeps them valid until the kernels have consumed them

@@ -75,6 +75,14 @@ def test_argument_validation_without_gpu(lib):
     lib.ml2048_timer_destroy(None)
     assert lib.ml2048_sched_stream_take(None, None, 0, None, None, None, None, None, None, None, None) == -1
     assert lib.ml2048_sched_stream_take_slot(None, None, None, None, None, None, None, None, None, None) == -1
+    # host-side plumbing of the pipelined rollout: NULL handles are rejected, nothing touches a device
+    assert lib.ml2048_event_create(None) == -1 and lib.ml2048_event_record(None, None) == -1
+    assert lib.ml2048_event_query(None) == -1 and lib.ml2048_event_synchronize(None) == -1
+    assert lib.ml2048_stream_wait_event(None, None) == -1
+    lib.ml2048_event_destroy(None)
+    assert lib.ml2048_rollout_chain_ids(None, 64, 0, C.byref(ok), 8, 4096, 4096, 1, 4096, 0, 0, 0, 0, 4096, 4096, None, None,
+                                        0, 0, None, 8192, 4096, 4096, 4096, None) == -1   # side-stream scan without a marker
+    assert b"rollout_event" in lib.ml2048_last_error()
     assert lib.ml2048_sched_stream_slot_bytes(0) == 0
     assert lib.ml2048_sched_stream_slot_bytes(128) == 1536 + 528 + 129 * 1024 * 16
     assert not lib.ml2048_sched_stream_create_pinned(None, None, None, 0, 128, 0.8, 4, None, 0)

@@ -13,3 +13,4 @@ print("%-34s value %.4g  ms/step %.4f  kernel us %.2f  frac %s" % (sys.argv[1] o
       (r.get("avg_launch_ms") or 0) * 1e3, r.get("frac")), flush=True)
 PY
 done
+python tools/debug/profile_rollout_host.py > gpurun_out/quick/host.log 2>&1; sed -n 2,3p gpurun_out/quick/host.log
