@@ -112,6 +112,32 @@ def test_plain_2m_boards_large_pass(amd, oracle):
     _run(amd, oracle, 2097152, [128], "normal", "host-async", 1)
 
 
+def test_plain_chain_with_the_copying_schedule_hand_over(amd, oracle, monkeypatch):
+    """ML2048_STREAM_PINNED=0: the schedule stream owns its slots and every schedule is copied into a pinned staging ring
+    (the fallback when the slots would not fit the pinned budget: very long rollouts) - same launches, same results."""
+    monkeypatch.setenv("ML2048_STREAM_PINNED", "0")
+    _run(amd, oracle, 4099, [128, 128, 65, 65], "improved", "host-async", 9, ids="deferred")
+
+
+def test_plain_chain_without_the_id_scan_then_with(amd, oracle):
+    """finish_ids=False leaves ids and the game counter alone (the caller numbers the games later or not at all); the
+    boards, flags and last-deal steps are those of the numbered run."""
+    M, N = 8192, 128
+    a = amd.VecGame(M, "normal", schedule="host-async")
+    b = amd.VecGame(M, "normal", schedule="host-async")
+    a.reset(5)
+    b.reset(5)
+    oa = a.rollout(N, masked=False, act_seed=ACT_SEED, act_counter=0, finish_ids=False)
+    ob = b.rollout(N, masked=False, act_seed=ACT_SEED, act_counter=0, finish_ids=True)
+    assert oa["step_resets"] is None and ob["step_resets"].shape == (N,)
+    assert set(oa) == set(ob) == {"actions", "digests", "step_resets", "reset_flags", "last_reset"}
+    assert np.array_equal(oa["reset_flags"].cpu().numpy(), ob["reset_flags"].cpu().numpy())
+    assert np.array_equal(oa["last_reset"].cpu().numpy(), ob["last_reset"].cpu().numpy())
+    assert np.array_equal(a.board.cpu().numpy(), b.board.cpu().numpy())
+    assert int(ob["step_resets"].sum().item()) == b._game_count   # every deal of the window, the first M included
+    assert a._game_count == 0                                     # nothing was numbered
+
+
 # ---- the same kernels on the plain 16-byte table layout (schedule="host": ml2048_rollout, probing spawn) -----------
 @pytest.mark.parametrize("M,lengths,reward,counter0", [
     (65536, [128, 65], "maxcell", 9),
