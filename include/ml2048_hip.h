@@ -219,7 +219,8 @@ int ml2048_sched_stream_release(ml2048_sched_stream *s);
  *     [ int32[n_steps][3] schedule, padded to 16 B | uint32[n_steps + 1] two-masks, padded | n_epochs x 1024 x 16 tables ]
  * (ml2048_sched_stream_slot_bytes(n_steps) bytes at most).  create_pinned lets the CALLER provide the `depth` slot
  * buffers - pinned host memory that a GPU copy kernel (ml2048_upload / ml2048_rollout_chain) reads in place, so that
- * handing a schedule to the device copies nothing on the host:
+ * handing a schedule to the device copies nothing on the host (the buffers must stay valid until
+ * ml2048_sched_stream_destroy has returned; take_slot on a stream without caller buffers is ML2048_E_UNSUPPORTED):
  *   take_slot   the next schedule in draw order, NOT released: *slot = which buffer, *n_epochs, *o_mask / *o_tab = byte
  *               offsets of the masks / tables, *nbytes = bytes in use; the 20 KB of after-state (generator, counter,
  *               tables after the schedule) are copied out (randperm_after / randfloat_after may be NULL).  Up to

@@ -121,6 +121,10 @@ def test_take_copies_the_slot_layout():
     c = _state_of(a)
     h = L.ml2048_sched_stream_create(C.byref(c), a.randperm.ctypes.data, a.randfloat.ctypes.data, a.rand_step, N, 0.8, 2)
     assert h
+    k, e = C.c_int32(0), C.c_int32(0)
+    q = [C.c_int64(0) for _ in range(3)]
+    assert L.ml2048_sched_stream_take_slot(h, C.byref(k), C.byref(e), C.byref(q[0]), C.byref(q[1]), C.byref(q[2]), None, None,
+                                           None, None) == -3   # this stream owns its slots: nothing to hand out in place
     dst = np.zeros(int(L.ml2048_sched_stream_slot_bytes(N)) + 16, np.uint8)
     off = (-dst.ctypes.data) % 16
     try:
