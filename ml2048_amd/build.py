@@ -59,11 +59,13 @@ def build(force: bool = False, verbose: bool = False, extra_hipcc_flags=(), out:
         subprocess.check_call(cmd)
         objs.append(obj)
         if os.path.basename(src) == "ml2048_hip.hip":
-            # two more passes over the same file: only the plain rollout instantiations and their launcher, once
-            # scheduled with max-ilp (5 % faster at C2) and once with the default strategy (3 % faster at 1 M
-            # boards); see ml2048_plain_launch in the source
-            ilp = os.environ.get("ML2048_SCHED_PLAIN", "max-ilp")  # A/B: another strategy for the small-M pass
-            for tag, flags in (("ilp", ["-mllvm", f"-amdgpu-sched-strategy={ilp}", "-DML2048_LONE_WAVE=1"]), ("dflt", [])):
+            # three more passes over the same file: only the plain rollout instantiations and their launcher - the
+            # lone-wave forms for small M scheduled with max-ilp (masked sampling, rocRAND mode) and with the default
+            # strategy (unmasked table mode: 2 % faster at C2), and the general forms for large M (default strategy,
+            # 3 % faster at 1 M boards than max-ilp); see ml2048_plain_launch in the source
+            ilp = os.environ.get("ML2048_SCHED_PLAIN", "max-ilp")  # A/B: another strategy for the small-M max-ilp pass
+            for tag, flags in (("ilp", ["-mllvm", f"-amdgpu-sched-strategy={ilp}", "-DML2048_LONE_WAVE=1"]),
+                               ("lone", ["-DML2048_LONE_WAVE=1"]), ("dflt", [])):
                 obj2 = os.path.splitext(src)[0] + f".plain_{tag}" + suffix
                 cmd2 = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                         f"-DML2048_ROLLOUT_PLAIN_TU=ml2048_internal_launch_rollout_plain_{tag}", *flags,

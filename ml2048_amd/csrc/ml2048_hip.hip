@@ -24,13 +24,20 @@
 using namespace ml2048;
 using namespace ml2048::dev;
 
-// The plain (no optional outputs) rollout instantiations are compiled in two further passes over this same file
-// (build.py: -DML2048_ROLLOUT_PLAIN_TU=<launcher name> with and without -mllvm -amdgpu-sched-strategy=max-ilp).
-// Same-box A/B of that scheduling strategy on them: C2 (one wave per SIMD) 105.7 -> 101.0 us - fewer s_nop between
-// v_cmp and v_cndmask, independent chains interleaved; 262 144 boards 249.9 -> 248.6 us; 1 M boards 852 -> 880 us
-// (with several waves per SIMD the hardware interleaves already and the longer live ranges cost); and 9-20 % slower
-// on the trajectory-writing instantiations.  It is a per-file flag, hence the passes; the first pass picks the
-// launcher by the number of boards and instantiates only the EXTRAS kernels itself.
+// The plain (no optional outputs) rollout instantiations are compiled in three further passes over this same file
+// (build.py: -DML2048_ROLLOUT_PLAIN_TU=<launcher name>; a scheduling strategy is a per-file flag, hence the passes; the
+// first pass picks the launcher and instantiates only the EXTRAS kernels itself):
+//   _ilp   small M (one wave per SIMD): the lone-wave forms (ML2048_LONE_WAVE) + -mllvm -amdgpu-sched-strategy=max-ilp;
+//   _lone  the same forms with the default strategy;
+//   _dflt  large M: the general forms, default strategy.
+// Same-box A/B of max-ilp: round 1's kernel at C2 105.7 -> 101.0 us (fewer s_nop between v_cmp and v_cndmask,
+// independent chains interleaved); 1 M boards 852 -> 880 us (with several waves per SIMD the hardware interleaves
+// already and the longer live ranges cost); 9-20 % slower on the trajectory-writing instantiations.  With round 2's
+// shorter lazy loop (dot-product spawn, position-mask compaction) the default strategy is the faster one for UNMASKED
+// table-mode rollouts (70.6 vs 72.1 us at C2, 106.0 vs 106.9 at 131 072 boards; max-memory-clause / iterative-maxocc the
+// same, iterative-minreg 73.2), while the masked loop (102.2 vs 103.8 us) and the rocRAND mode (97.4 vs 98.0) still
+// prefer max-ilp - both loops live in one kernel function, so the choice is made per launch: _lone for unmasked table
+// mode, _ilp otherwise (tools/debug/ab_multi.sh).
 struct ml2048_plain_launch {
     dim3 grid, block;
     hipStream_t stream;
@@ -56,6 +63,8 @@ struct ml2048_plain_launch {
 };
 __attribute__((visibility("hidden"))) int ml2048_internal_launch_rollout_plain_ilp(int reward_kind, bool fast, bool inv_tables,
                                                                                    const ml2048_plain_launch &a);
+__attribute__((visibility("hidden"))) int ml2048_internal_launch_rollout_plain_lone(int reward_kind, bool fast, bool inv_tables,
+                                                                                    const ml2048_plain_launch &a);
 __attribute__((visibility("hidden"))) int ml2048_internal_launch_rollout_plain_dflt(int reward_kind, bool fast, bool inv_tables,
                                                                                     const ml2048_plain_launch &a);
 
@@ -1772,7 +1781,7 @@ __attribute__((visibility("hidden"))) bool ml2048_internal_take_timer(hipEvent_t
 }
 extern "C" {
 
-// largest M that runs the max-ilp build of the plain rollout kernels (see ml2048_plain_launch); ML2048_PLAIN_ILP_MAX
+// largest M that runs the small-M builds of the plain rollout kernels (see ml2048_plain_launch); ML2048_PLAIN_ILP_MAX
 // overrides it for A/B runs
 static int64_t plain_ilp_max_boards() {
     static const int64_t v = [] {
@@ -1826,8 +1835,10 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
         a.reset_flags = reset_flags, a.flag_words = W, a.last_reset = last_reset;
         a.spawn_seed = spawn_seed, a.spawn_counter0 = spawn_counter0, a.two_threshold = thr;
         a.up_src = (const uint4 *)up_src, a.up_dst = (uint4 *)up_dst, a.up_n16 = up_n16, a.up_blocks = up_blocks, a.up_tab16 = up_tab16;
-        if (M <= plain_ilp_max_boards() ? ml2048_internal_launch_rollout_plain_ilp(reward_kind, fast, inv_tables, a)
-                                    : ml2048_internal_launch_rollout_plain_dflt(reward_kind, fast, inv_tables, a))
+        const bool small = M <= plain_ilp_max_boards();
+        if (small ? (!fast && !masked ? ml2048_internal_launch_rollout_plain_lone(reward_kind, fast, inv_tables, a)
+                                      : ml2048_internal_launch_rollout_plain_ilp(reward_kind, fast, inv_tables, a))
+                  : ml2048_internal_launch_rollout_plain_dflt(reward_kind, fast, inv_tables, a))
             return fail(ML2048_E_INVALID, "reward_kind=%d", reward_kind);
         return check_launch("ml2048_rollout");
     }
