@@ -1786,7 +1786,7 @@ extern "C" {
 static int64_t plain_ilp_max_boards() {
     static const int64_t v = [] {
         const char *e = getenv("ML2048_PLAIN_ILP_MAX");
-        return e ? (int64_t)atoll(e) : (int64_t)131072;
+        return e ? (int64_t)atoll(e) : (int64_t)196608; // up to three waves per SIMD (tools/debug/ilpmax_ab.sh)
     }();
     return v;
 }

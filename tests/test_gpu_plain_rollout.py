@@ -3,7 +3,8 @@
 `VecGame.rollout()` without `record_actions / digests / trajectory` launches `k_rollout<KIND, FAST, EXTRAS=false, INV>`
 (csrc/ml2048_hip.hip): lazy valid-mask loop, eight steps per loop iteration, inverse-permutation spawn on the
 expanded tables of the chained upload (`ml2048_rollout_chain`), and one of two separately compiled passes chosen by
-the board count (M <= 131 072: max-ilp scheduling + the lone-wave forms; larger M: default scheduling).  None of
+the board count (M <= 196 608: the lone-wave forms, default scheduling - max-ilp for masked sampling and the rocRAND mode;
+larger M: the general forms).  None of
 that code runs in the EXTRAS=true instantiation the digest-checking tests of test_gpu_parity.py use.
 
 The actions of such a rollout are a pure function of (act_seed, act_counter + t, board index) - and of the valid
@@ -97,8 +98,8 @@ def test_plain_c2_twice_back_to_back(amd, oracle):
 
 @pytest.mark.parametrize("M,lengths,reward,counter0", [
     (65536, [127, 65, 200], "improved", 13),   # remainder loop of the 8-step unroll; 64-step flag chunk edges
-    (131072, [128, 64], "rank", 0),            # largest M of the small-M pass
-    (131073, [128, 65], "maxcell", 77),        # smallest M of the large-M pass, ragged tail wave
+    (196608, [128, 64], "rank", 0),            # largest M of the small-M passes (three waves per SIMD)
+    (196609, [128, 65], "maxcell", 77),        # smallest M of the large-M pass, ragged tail wave
     (262144, [128, 128], "normal", 3),         # C4's per-GPU shard / C3's size
     (1000, [200, 65, 1], "improved", 31),      # ragged small M
     (63, [130], "rank", 5),
