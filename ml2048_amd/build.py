@@ -64,8 +64,10 @@ def build(force: bool = False, verbose: bool = False, extra_hipcc_flags=(), out:
             # strategy (unmasked table mode: 2 % faster at C2), and the general forms for large M (default strategy,
             # 3 % faster at 1 M boards than max-ilp); see ml2048_plain_launch in the source
             ilp = os.environ.get("ML2048_SCHED_PLAIN", "max-ilp")  # A/B: another strategy for the small-M max-ilp pass
+            large = os.environ.get("ML2048_SCHED_LARGE", "default")  # A/B: a strategy for the large-M pass
+            large_flags = [] if large == "default" else ["-mllvm", f"-amdgpu-sched-strategy={large}"]
             for tag, flags in (("ilp", ["-mllvm", f"-amdgpu-sched-strategy={ilp}", "-DML2048_LONE_WAVE=1"]),
-                               ("lone", ["-DML2048_LONE_WAVE=1"]), ("dflt", [])):
+                               ("lone", ["-DML2048_LONE_WAVE=1"]), ("dflt", large_flags)):
                 obj2 = os.path.splitext(src)[0] + f".plain_{tag}" + suffix
                 cmd2 = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                         f"-DML2048_ROLLOUT_PLAIN_TU=ml2048_internal_launch_rollout_plain_{tag}", *flags,
