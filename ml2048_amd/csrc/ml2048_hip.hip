@@ -807,6 +807,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
     // there and 1 % more at 1 M boards (two more VALU per step where other waves hid the LDS write anyway).
 #ifdef ML2048_LONE_WAVE
     uint32_t park_lo = 0, park_hi = 0;
+    const unsigned long long live_lanes = __builtin_amdgcn_ballot_w64((int64_t)blockIdx.x * kBlock + threadIdx.x < M);
 #else
     __shared__ unsigned long long flag_park[kBlock / 64][kFlagChunk];
 #endif
@@ -853,6 +854,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
     // draw two bits of W(t >> 4).  aw[0] is always the current word; one Philox block serves 4 masked or 64 plain
     // steps.  `seq_shift` = log2(draws per word).
     uint32_t aw[4];
+    uint32_t act_bits = 0; // lazy loop: what is left of the current word after the draws made so far
     {
         const uint32_t seq_shift = masked ? 0u : 4u;
         const uint64_t j0 = act_counter0 >> seq_shift;
@@ -1027,7 +1029,13 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                 }
                 // ---- prepare (game_numba.py:619-658)
                 const bool deal = s.terminated != 0;
-                const unsigned long long dealt = __ballot(deal && live);
+                // (the builtin on the bool itself: __ballot(int) first turns the predicate into 0/1 with a select and
+                // compares that again - two VALU slots per step for a lone wave)
+#ifdef ML2048_LONE_WAVE
+                const unsigned long long dealt = __builtin_amdgcn_ballot_w64(deal); // the tail lanes are masked at the flush
+#else
+                const unsigned long long dealt = __builtin_amdgcn_ballot_w64(deal && live);
+#endif
 #ifdef ML2048_LONE_WAVE
                 write_lane64(park_lo, park_hi, dealt, t - t0);
 #else
@@ -1059,10 +1067,17 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                     last = t;
                 }
                 // ---- sample (policy/random.py:17-27)
+                uint32_t word;
+                if constexpr (!WORD_CHECK) {
+                    // inside a group of the lazy loop: the draws of this group are the next bits of `act_bits`, which
+                    // the group's first step left behind - no counter arithmetic at all (three scalar slots per step)
+                    word = act_bits;
+                    act_bits >>= 2;
+                } else {
                 const uint64_t tt = act_counter0 + (uint64_t)t;
                 const bool plain = LAZY || !masked; // two bits per draw; LAZY instantiations are never masked
                 const uint32_t sub = plain ? (uint32_t)(tt & 15ull) : 0u;
-                if (WORD_CHECK && t > 0 && sub == 0) { // wave-uniform: the next word of the stream
+                if (t > 0 && sub == 0) { // wave-uniform: the next word of the stream
                     const uint64_t j = plain ? (tt >> 4) : tt;
                     if ((j & 3ull) == 0) {
                         rocrand_state_philox4x32_10 rs;
@@ -1073,7 +1088,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                         aw[0] = aw[1]; aw[1] = aw[2]; aw[2] = aw[3];
                     }
                 }
-                const uint32_t word = aw[0] >> (2u * sub);
+                word = aw[0] >> (2u * sub);
+                act_bits = word >> 2;
+                }
                 uint32_t cnt = 4;
                 const uint32_t action = LAZY ? (word & 3u) : pick_action(s.valid, word, masked, cnt);
                 if (EXTRAS && actions_out && live) actions_out[(int64_t)t * M + i] = (uint8_t)action;
@@ -1172,8 +1189,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
             for (; t < t1; ++t) one_step(t, std::true_type{});
 #ifdef ML2048_LONE_WAVE
             // flush this chunk's re-deal flags: lane q holds step t0 + q
-            if (lane < t1 - t0)
-                reset_flags[(int64_t)(t0 + lane) * flag_words + wave_global] = (uint64_t)park_lo | ((uint64_t)park_hi << 32);
+            if (lane < t1 - t0) // (lanes past M shadow the last board, re-deals included: not boards, not flags)
+                reset_flags[(int64_t)(t0 + lane) * flag_words + wave_global] =
+                    ((uint64_t)park_lo | ((uint64_t)park_hi << 32)) & live_lanes;
 #else
             // flush this chunk's re-deal flags (wave-private LDS row: a wave-scope fence is enough)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
