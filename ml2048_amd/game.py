@@ -527,7 +527,8 @@ class VecGame:
                     self._two_prob, depth, ptrs, sb)
                 self._ss_slots = [[mem[k * sb:(k + 1) * sb], None, np.empty((RAND_SIZE, 16), np.uint8),
                                    np.empty((RAND_SIZE,), np.float32)] for k in range(depth)]
-                self._ss_hold = max(2, depth - 3)  # slots left to the producer: the rest
+                # slots the launch thread may hold (= rollouts it may run ahead of the GPU); the rest is the producer's room
+                self._ss_hold = min(depth - 1, max(2, int(os.environ.get("ML2048_STREAM_HOLD", str(depth - 3)))))
                 self._ss_taken = 0
             else:
                 self._sstream = L.ml2048_sched_stream_create(C.byref(c), self._rng.randperm.ctypes.data,
