@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import subprocess
@@ -309,6 +310,12 @@ def main():
 
     def measure(step_fn, k, w):
         """w untimed + k timed bench steps, barrier + synchronize on both sides, max over ranks."""
+        # Everything alive now is set-up that lives as long as the run: collect once and move it out of the cyclic
+        # collector's sight.  A full collection with torch imported takes ~40 ms (tools/debug/hiccup_trace.py: one per
+        # run, around the 750th rollout) - 500 rollouts' worth of a launch thread that has to stay ahead of a 70 us
+        # kernel; after the freeze a collection only walks what the loop itself allocated.
+        gc.collect()
+        gc.freeze()
         for _ in range(w):
             step_fn(False)
         barrier()
