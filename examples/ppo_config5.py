@@ -236,6 +236,9 @@ def main():
     obs = torch.empty((M, 16, 4, 4), dtype=torch.float32, device=dev)
     log = []
     env_time = net_time = train_time = 0.0
+    import gc
+    gc.collect()
+    gc.freeze()  # the set-up above lives as long as the run: keep it out of the cyclic collector's sight (README.md)
     for epoch in range(args.epochs):
         net_eval.load_state_dict(net.state_dict())
         stats.reset()
