@@ -1,6 +1,7 @@
 """Build libml2048_hip.so (gfx950) in-tree with hipcc.  `python -m ml2048_amd.build`."""
 from __future__ import annotations
 
+import concurrent.futures
 import os
 import shutil
 import subprocess
@@ -38,26 +39,19 @@ def build(force: bool = False, verbose: bool = False, extra_hipcc_flags=(), out:
             return LIB_PATH
     lib_path = out or LIB_PATH
     suffix = ".ab.o" if out else ".o"
-    objs = []
+    jobs = []  # (command, object): independent compilations, run a few at a time (the big file is compiled four times)
     for src in HOST_SOURCES:
         obj = os.path.splitext(src)[0] + suffix
-        cmd = [os.environ.get("CXX", "g++"), "-O2", "-mssse3", "-std=c++17", "-fPIC", "-fopenmp", "-pthread", "-c", src, "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        objs.append(obj)
+        jobs.append(([os.environ.get("CXX", "g++"), "-O2", "-mssse3", "-std=c++17", "-fPIC", "-fopenmp", "-pthread", "-c", src,
+                      "-o", obj], obj))
     for src in SOURCES:
         obj = os.path.splitext(src)[0] + suffix
         # ML2048_SCHED=<strategy> (A/B only) applies a scheduling strategy to whole files; the default build uses
         # max-ilp for the plain rollout kernels alone (the extra passes below)
         sched = os.environ.get("ML2048_SCHED", "default")
         sched_flags = [] if sched == "default" else ["-mllvm", f"-amdgpu-sched-strategy={sched}"]
-        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *sched_flags, *extra_hipcc_flags,
-               "-c", src, "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        objs.append(obj)
+        jobs.append(([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *sched_flags, *extra_hipcc_flags,
+                      "-c", src, "-o", obj], obj))
         if os.path.basename(src) == "ml2048_hip.hip":
             # three more passes over the same file: only the plain rollout instantiations and their launcher - the
             # lone-wave forms for small M scheduled with max-ilp (masked sampling, rocRAND mode) and with the default
@@ -69,13 +63,19 @@ def build(force: bool = False, verbose: bool = False, extra_hipcc_flags=(), out:
             for tag, flags in (("ilp", ["-mllvm", f"-amdgpu-sched-strategy={ilp}", "-DML2048_LONE_WAVE=1"]),
                                ("lone", ["-DML2048_LONE_WAVE=1"]), ("dflt", large_flags)):
                 obj2 = os.path.splitext(src)[0] + f".plain_{tag}" + suffix
-                cmd2 = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-                        f"-DML2048_ROLLOUT_PLAIN_TU=ml2048_internal_launch_rollout_plain_{tag}", *flags,
-                        *extra_hipcc_flags, "-c", src, "-o", obj2]
-                if verbose:
-                    print(" ".join(cmd2), flush=True)
-                subprocess.check_call(cmd2)
-                objs.append(obj2)
+                jobs.append(([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+                              f"-DML2048_ROLLOUT_PLAIN_TU=ml2048_internal_launch_rollout_plain_{tag}", *flags,
+                              *extra_hipcc_flags, "-c", src, "-o", obj2], obj2))
+
+    def run(job):
+        if verbose:
+            print(" ".join(job[0]), flush=True)
+        subprocess.check_call(job[0])
+        return job[1]
+
+    workers = max(1, min(len(jobs), int(os.environ.get("ML2048_BUILD_JOBS", str(min(4, os.cpu_count() or 1))))))
+    with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as pool:
+        objs = list(pool.map(run, jobs))  # in job order: the link line does not depend on who finished first
     cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", lib_path, *objs, "-lgomp", "-lpthread"]
     if verbose:
         print(" ".join(cmd), flush=True)
