@@ -831,6 +831,25 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
         return;
     }
 
+#if defined(ML2048_LONE_WAVE) && (!defined(ML2048_SCHED_AHEAD) || ML2048_SCHED_AHEAD)
+    // The lane-held schedule of a 64-step chunk (see run_steps): its entries are requested a chunk ahead - the first
+    // chunk's here, in front of the record's loads, the next chunk's at the start of the chunk before it - and only the
+    // dependent gather of the entries' two-masks is left for the chunk's own start (one exposed round trip per chunk
+    // instead of two; ML2048_SCHED_AHEAD=0: A/B).
+    constexpr bool SCHED_AHEAD = !FAST && !EXTRAS;
+    uint32_t nx_e = 0, nx_rp = 0, nx_rs = 0; // lane q: entry (chunk start + q + 1), epoch clamped
+    auto fetch_chunk_entries = [&](int t0c) __attribute__((always_inline)) {
+        const int j = t0c + lane + 1 < N ? t0c + lane + 1 : N - 1;
+        const uint32_t e = (uint32_t)schedule[3 * j + 0];
+        const uint32_t cap = (uint32_t)(n_epochs - 1);
+        nx_e = e < cap ? e : cap;
+        nx_rp = (uint32_t)schedule[3 * j + 1];
+        nx_rs = (uint32_t)schedule[3 * j + 2];
+    };
+    if (SCHED_AHEAD) fetch_chunk_entries(0);
+#elif defined(ML2048_LONE_WAVE)
+    constexpr bool SCHED_AHEAD = false;
+#endif
     StepRegs s;
     s.board = load_board(st.board, ii);
     {
@@ -955,13 +974,24 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
             uint32_t sch_eo = 0, sch_rp = 0, sch_rs = 0, sch_tm = 0;
             const uint32_t row_lane = (uint32_t)(idx_base + ii); // only its low 10 bits matter
             if (!FAST && VPF) {
-                const int j = t0 + lane + 1 < N ? t0 + lane + 1 : N - 1;
-                const uint32_t e = (uint32_t)schedule[3 * j + 0];
-                const uint32_t ec = e < e_last ? e : e_last;
-                sch_eo = ec * (uint32_t)kEpochBytes;
-                sch_rp = (uint32_t)schedule[3 * j + 1];
-                sch_rs = (uint32_t)schedule[3 * j + 2];
-                sch_tm = two_masks[ec];
+#if !defined(ML2048_SCHED_AHEAD) || ML2048_SCHED_AHEAD
+                if (SCHED_AHEAD) {
+                    sch_eo = nx_e * (uint32_t)kEpochBytes;
+                    sch_rp = nx_rp;
+                    sch_rs = nx_rs;
+                    sch_tm = two_masks[nx_e];
+                    if (t0 + kFlagChunk < N) fetch_chunk_entries(t0 + kFlagChunk); // wave-uniform; used a chunk later
+                } else
+#endif
+                {
+                    const int j = t0 + lane + 1 < N ? t0 + lane + 1 : N - 1;
+                    const uint32_t e = (uint32_t)schedule[3 * j + 0];
+                    const uint32_t ec = e < e_last ? e : e_last;
+                    sch_eo = ec * (uint32_t)kEpochBytes;
+                    sch_rp = (uint32_t)schedule[3 * j + 1];
+                    sch_rs = (uint32_t)schedule[3 * j + 2];
+                    sch_tm = two_masks[ec];
+                }
             }
 #endif
             auto one_step = [&](const int t, auto word_check_tag) __attribute__((always_inline)) {
