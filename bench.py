@@ -73,8 +73,10 @@ def parse():
     ap.add_argument("--ids", choices=["deferred", "inline"], default="deferred",
                     help="fused mode: where the ordered game-id scan of a rollout runs - 'deferred' = on a side "
                          "stream beside the next rollout's kernel, 'inline' = on the launch stream")
-    ap.add_argument("--event-every", type=int, default=8,
-                    help="attach a HIP event pair to every k-th timed launch of the dominant kernel")
+    ap.add_argument("--event-every", type=int, default=0,
+                    help="attach a HIP event pair to every k-th timed launch of the dominant kernel (0 = auto: about 32 "
+                         "samples per measurement, never more often than every 8th launch - a timed launch costs ~8 us "
+                         "end to end, tools/debug/event_ab.sh)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for the barrier / max-over-ranks (nccl = RCCL; gloo only for "
                          "rehearsing the N>1 launch contract on a box with fewer GPUs than ranks)")
@@ -319,9 +321,10 @@ def main():
         for _ in range(w):
             step_fn(False)
         barrier()
+        every = args.event_every if args.event_every > 0 else max(8, k // 32)
         t0 = time.perf_counter()
         for i in range(k):
-            step_fn(i % max(1, args.event_every) == 0)
+            step_fn(i % every == every // 2)  # (not the window's first launch: it starts on an idle GPU)
         barrier()
         return max_over_ranks(time.perf_counter() - t0, dist)
 
