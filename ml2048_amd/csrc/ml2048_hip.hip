@@ -1773,6 +1773,10 @@ struct ml2048_timer_impl {
     bool used;
 };
 static thread_local ml2048_timer_impl *g_armed_timer = nullptr;
+// ml2048_rollout_chain_ids: the rollout's marker event rides on the kernel's own dispatch (its completion signal)
+// instead of a marker packet behind it - one-shot, consumed by the next launch_rollout of this thread
+static thread_local hipEvent_t g_attach_stop_event = nullptr;
+static thread_local bool g_stop_event_attached = false;
 
 int ml2048_timer_create(void **timer) {
     if (!timer) return fail(ML2048_E_INVALID, "timer is NULL");
@@ -1873,6 +1877,12 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
     g_armed_timer = nullptr;
     hipEvent_t ev_start = timer ? timer->start : nullptr, ev_stop = timer ? timer->stop : nullptr;
     if (timer) timer->used = true;
+    g_stop_event_attached = false;
+    if (!timer && g_attach_stop_event) { // (a timed dispatch keeps its own pair: the caller records the marker then)
+        ev_stop = g_attach_stop_event;
+        g_stop_event_attached = true;
+    }
+    g_attach_stop_event = nullptr;
     if (inv_tables && (fast || extras)) return fail(ML2048_E_UNSUPPORTED, "expanded tables: plain table-mode rollouts only");
     if (!extras) { // the plain instantiations live in their own compilation passes (see ml2048_plain_launch)
         ml2048_plain_launch a;
@@ -2051,11 +2061,16 @@ int ml2048_rollout_chain_ids(void *stream, int64_t M, int64_t idx_base, const ml
     if (ids && ids_stream != stream && !rollout_event)
         return fail(ML2048_E_INVALID, "an id scan on another stream needs rollout_event to wait for");
     if (ids && !game_count) return fail(ML2048_E_INVALID, "game_count is NULL");
-    if (int rc = ml2048_rollout_chain(stream, M, idx_base, st, N, perm_epochs, two_masks, n_epochs, schedule, reward_kind, masked,
-                                      act_seed, act_counter0, reset_flags, last_reset, next_src_host, next_dst, next_nbytes,
-                                      next_table_offset))
-        return rc;
-    if (rollout_event)
+    // ML2048_ATTACH_EVENT=0 records the marker behind the kernel instead (A/B: tools/debug/attach_ab.sh - the marker
+    // packet costs ~2 us between two dependent rollout kernels, ~4 us per rollout in a 20-launch window)
+    static const bool attach = [] { const char *e = getenv("ML2048_ATTACH_EVENT"); return !e || atoi(e) != 0; }();
+    if (attach && rollout_event) g_attach_stop_event = (hipEvent_t)rollout_event;
+    const int rc0 = ml2048_rollout_chain(stream, M, idx_base, st, N, perm_epochs, two_masks, n_epochs, schedule, reward_kind, masked,
+                                         act_seed, act_counter0, reset_flags, last_reset, next_src_host, next_dst, next_nbytes,
+                                         next_table_offset);
+    g_attach_stop_event = nullptr;
+    if (rc0) return rc0;
+    if (rollout_event && !g_stop_event_attached)
         if (int rc = ml2048_event_record(rollout_event, stream)) return rc;
     if (!ids) return 0;
     if (ids_stream != stream)
