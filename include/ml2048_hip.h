@@ -356,8 +356,13 @@ int ml2048_rollout_chain(void *stream, int64_t M, int64_t idx_base, const ml2048
  * kernel, then - when scratch != NULL - ml2048_rollout_finish_ids on ids_stream (== stream: inline; another stream:
  * it first waits for rollout_event, so the scan runs beside whatever `stream` does next) and ids_done_event (may be
  * NULL) recorded behind the scan.  One call instead of five: the host side of a 70 us kernel has to stay well below it.
+ * rollout_event is not recorded as a marker packet but attached to the kernel's dispatch as its completion event
+ * (hipExtLaunchKernel's stop event): between two dependent rollout kernels a marker costs ~2 us.  The same is available
+ * to the other rollout entry points through ml2048_rollout_attach_event.
  * (No counterpart in the reference, whose loop is synchronous Python, runner.py:74-117.)
  */
+int ml2048_rollout_attach_event(void *event); /* one-shot, per thread: the next ml2048_rollout* launch completes `event` */
+int ml2048_rollout_event_attached(void);      /* 1 = the last rollout launch of this thread carried the attached event */
 int ml2048_event_create(void **event);
 void ml2048_event_destroy(void *event);
 int ml2048_event_record(void *event, void *stream);

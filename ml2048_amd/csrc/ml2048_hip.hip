@@ -2051,6 +2051,17 @@ int ml2048_stream_wait_event(void *stream, void *event) {
 
 // ml2048_rollout_chain + the marker behind its kernel + ml2048_rollout_finish_ids (on the same or on a side stream) in
 // ONE call: what VecGame.rollout() issues per plain rollout, without a Python round trip per piece
+// One-shot, per thread: the next ml2048_rollout* launch carries `event` as its dispatch's completion event (no marker
+// packet behind the kernel).  ml2048_rollout_event_attached() tells whether that launch did (a timed dispatch keeps its
+// timer's pair; then the caller records the event itself).
+int ml2048_rollout_attach_event(void *event) {
+    if (!event) return fail(ML2048_E_INVALID, "event is NULL");
+    g_attach_stop_event = (hipEvent_t)event;
+    return 0;
+}
+
+int ml2048_rollout_event_attached(void) { return g_stop_event_attached ? 1 : 0; }
+
 int ml2048_rollout_chain_ids(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
                              const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,
                              const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0,

@@ -1185,6 +1185,11 @@ class VecGame:
                 kernel_events[0].record(torch.cuda.current_stream(dev))
             if kernel_timer is not None:
                 _lib.check(L.ml2048_timer_arm(kernel_timer), "timer_arm")
+            roll_ev = None
+            if (not fast and not on_device and staged) or finish_ids == "deferred":
+                roll_ev = self._next_roll_event()
+                if kernel_events is None:  # (markers around the kernel are wanted: then this one is a marker too)
+                    _lib.check(L.ml2048_rollout_attach_event(roll_ev.h), "rollout_attach_event")
             if trajectory is not None:
                 if fast or record_actions or digests:
                     raise ValueError("trajectory= is for table spawn mode, without record_actions/digests")
@@ -1231,12 +1236,11 @@ class VecGame:
                 self._sched_pending_slot["free"] = ev
             if kernel_events is not None:
                 kernel_events[1].record(torch.cuda.current_stream(dev))
-            roll_ev = None
-            if (not fast and not on_device and staged) or finish_ids == "deferred":
-                # ONE marker per rollout, right after its kernel: it frees the pinned buffers the launch
-                # read and is what a deferred id scan waits for (every marker costs GPU time between kernels)
-                roll_ev = self._next_roll_event()
-                roll_ev.record(self._raw_stream())
+            if roll_ev is not None:
+                # ONE marker per rollout: it frees the pinned buffers the launch read and is what a deferred id scan
+                # waits for.  It rode on the kernel's own dispatch (see above) unless that dispatch was a timed one.
+                if not L.ml2048_rollout_event_attached():
+                    roll_ev.record(self._raw_stream())
                 if not fast and not on_device:
                     for ps in staged:
                         ps[1] = roll_ev

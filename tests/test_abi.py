@@ -80,6 +80,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ml2048_event_query(None) == -1 and lib.ml2048_event_synchronize(None) == -1
     assert lib.ml2048_stream_wait_event(None, None) == -1
     lib.ml2048_event_destroy(None)
+    assert lib.ml2048_rollout_attach_event(None) == -1 and lib.ml2048_rollout_event_attached() == 0
     assert lib.ml2048_rollout_chain_ids(None, 64, 0, C.byref(ok), 8, 4096, 4096, 1, 4096, 0, 0, 0, 0, 4096, 4096, None, None,
                                         0, 0, None, 8192, 4096, 4096, 4096, None) == -1   # side-stream scan without a marker
     assert b"rollout_event" in lib.ml2048_last_error()
