@@ -258,7 +258,7 @@ class VecGame:
         self._ids_pending = False   # wait for it before anything touches ids / the game counter
         self._spin = [None, None, None, None]  # pinned staging ring: [tensor, event of the launch that reads it]
         self._spin_i = 0
-        self._roll_ev = None        # ring of per-rollout events (ONE record per rollout, after its kernel)
+        self._roll_ev = None        # ring of per-rollout events (ONE per rollout: the kernel's own completion event)
         self._plain_layouts = {}    # (M, N) -> offsets inside a plain rollout's one device allocation
         self._roll_i = 0
         self._sdev = [None, None]   # device-side packed schedules (the resident one and the next one)
@@ -329,7 +329,7 @@ class VecGame:
     def _rollout_plain_chain(self, N, masked, act_seed, act_counter, finish_ids, kernel_timer, packed_ptr, o_mask, o_tab,
                              E, chain, staged):
         """The pipelined plain rollout (schedule="host-async", no optional outputs): ONE native call launches the kernel
-        with the next schedule's upload chained to it, records its marker and issues the id scan
+        with the next schedule's upload chained to it, attaches the rollout's event to that dispatch and issues the id scan
         (ml2048_rollout_chain_ids); ONE device allocation holds the re-deal flags, the last-deal steps, the per-step
         re-deal counts and the scan's scratch.  Everything here is on the critical path of a 70 us kernel."""
         L, M, dev = self._L, self._size, self.device
