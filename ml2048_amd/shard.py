@@ -38,14 +38,16 @@ def host_thread_plan(cpu_share: int, local_world: int, requested: str = "auto") 
     "cpus_per_rank": ...}.
 
     Every rank runs a Python thread, the HIP runtime's helper threads and (host-async) one stitcher besides the
-    workers, hence `share - 4`; more than 8 workers crowd those out (measured: 10-14 workers are slower than 8).
-    Measured per 128-step schedule on the GPU box's EPYC 9575F: 0.48 / 0.26 / 0.13 / 0.10 / 0.074 ms with
-    1 / 2 / 4 / 6 / 8 workers, against a 0.087 ms rollout kernel at 65 536 boards - so fewer than 6 workers make the
-    run host-bound, but it stays correct and pipelined.  "auto" never picks the schedule drawn on the GPU
+    workers, hence `share - 4`; more than 9 workers crowd those out on a 16-CPU share (measured end to end with the
+    0.068 ms kernel, five runs each: 9 workers 0.0698-0.0700 ms per rollout every time; 10 workers 0.0697-0.0734;
+    8 workers 0.0699-0.0776, producer-bound in three of five; 12-14 slower and erratic).
+    Measured per 128-step schedule on the GPU box's EPYC 9575F: 0.48 / 0.26 / 0.13 / 0.10 / 0.074 / 0.062 ms with
+    1 / 2 / 4 / 6 / 8 / 10 workers, against a 0.068 ms rollout kernel at 65 536 boards - so fewer than 9 workers make
+    the run host-bound, but it stays correct and pipelined.  "auto" never picks the schedule drawn on the GPU
     (`schedule="device"`, 0.128 ms per rollout with no host threads at all): that path is opt-in.  With fewer than
     3 CPUs per rank there is no room for producer threads: the synchronous native call."""
     per_rank = max(1, int(cpu_share) // max(1, int(local_world)))
-    threads = max(1, min(8, per_rank - 4))
+    threads = max(1, min(9, per_rank - 4))
     if requested != "auto":
         schedule = requested
     elif per_rank < 3:

@@ -6,7 +6,7 @@ import pytest
 from ml2048_amd.shard import host_thread_plan
 
 
-@pytest.mark.parametrize("cpus,threads", [(32, 1), (64, 4), (128, 8), (256, 8)])
+@pytest.mark.parametrize("cpus,threads", [(32, 1), (64, 4), (128, 9), (256, 9)])
 def test_plan_for_eight_ranks(cpus, threads):
     plan = host_thread_plan(cpus, 8)
     assert plan == {"threads": threads, "schedule": "host-async", "cpus_per_rank": cpus // 8}
@@ -16,7 +16,7 @@ def test_plan_for_eight_ranks(cpus, threads):
 
 
 def test_plan_single_rank_box_and_starved_ranks():
-    assert host_thread_plan(16, 1) == {"threads": 8, "schedule": "host-async", "cpus_per_rank": 16}   # the 1-GPU pool box
+    assert host_thread_plan(16, 1) == {"threads": 9, "schedule": "host-async", "cpus_per_rank": 16}   # the 1-GPU pool box
     assert host_thread_plan(8, 1)["threads"] == 4
     assert host_thread_plan(16, 8) == {"threads": 1, "schedule": "host", "cpus_per_rank": 2}          # no room for producers
     assert host_thread_plan(1, 8)["schedule"] == "host"
