@@ -483,7 +483,11 @@ def main():
                        "host_schedule": args.schedule, "ML2048_HOST_THREADS": int(os.environ["ML2048_HOST_THREADS"]),
                        "per_rank": per_rank, "id_scan": args.ids,
                        "spawn": "table (bit-exact with the reference's PCG64 tables)" if args.spawn == "table" else
-                                "rocrand (rocRAND Philox spawn: the same game statistically, not bit-exact with numba)"},
+                                "rocrand (rocRAND Philox spawn: the same game statistically, not bit-exact with numba)",
+                       "timing": "W warm-up steps (the first one carries a kernel timer, so the runtime's one-off set-up for "
+                                 "timed dispatches is not inside the timed region), barrier + synchronize, exactly K steps, "
+                                 "barrier + synchronize; gc.collect() + gc.freeze() before the warm-up; the kernel timer "
+                                 "rides on every max(8, K/32)-th timed launch"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         line.update(extras)
