@@ -363,6 +363,17 @@ int ml2048_rollout_chain(void *stream, int64_t M, int64_t idx_base, const ml2048
  */
 int ml2048_rollout_attach_event(void *event); /* one-shot, per thread: the next ml2048_rollout* launch completes `event` */
 int ml2048_rollout_event_attached(void);      /* 1 = the last rollout launch of this thread carried the attached event */
+
+/* The line table of the plain fused rollouts.  A line of four cells with exponents <= 15 is a 16-bit index and what
+ * _push_row (game_numba.py:48-90) makes of it a 16-bit value; the rollout kernels without optional outputs keep the
+ * 65 536 entries in LDS and move a board with four look-ups instead of ~85 vector instructions.  The table is constant
+ * data in a caller-owned device buffer of ML2048_ROW_LUT_BYTES (16-byte aligned), filled once by ml2048_row_lut_fill and
+ * handed to the next rollout launch of the calling thread by ml2048_rollout_attach_row_lut (one-shot; without it the
+ * launch computes the move arithmetically - same results).  A wave whose boards hold a tile above 2^11, or a rollout of
+ * more than 8 191 steps, takes the arithmetic move by itself. */
+#define ML2048_ROW_LUT_BYTES 131072
+int ml2048_row_lut_fill(void *stream, void *lut);
+int ml2048_rollout_attach_row_lut(const void *lut);
 int ml2048_event_create(void **event);
 void ml2048_event_destroy(void *event);
 int ml2048_event_record(void *event, void *stream);

@@ -133,6 +133,8 @@ _SIGNATURES = {
                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ml2048_rollout_attach_event": (C.c_int, [C.c_void_p]),
     "ml2048_rollout_event_attached": (C.c_int, []),
+    "ml2048_row_lut_fill": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ml2048_rollout_attach_row_lut": (C.c_int, [C.c_void_p]),
     "ml2048_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "ml2048_event_destroy": (None, [C.c_void_p]),
     "ml2048_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -233,6 +233,63 @@ ML_HD MoveResult move_board(const Board &in, uint32_t action) {
     return out;
 }
 
+// ---- the move by table look-up ---------------------------------------------------------------------------------------
+// A line of four cells with exponents <= 15 is a 16-bit index (cell k, counted from the side the tiles move to, in
+// nibble k) and what _push_row (:48-90) makes of it is a 16-bit value: 65 536 entries x 2 bytes = 128 KiB, which fits
+// the 160 KiB of LDS of a CDNA4 compute unit next to the rollout's 16 KiB of parked flags.  A fused rollout that keeps
+// nothing of a move but the board (the loops without reward arithmetic: score_potential) then moves four lines with four
+// ds_read_u16 and ~20 VALU around them instead of the ~85 VALU of compact_cells + merge marks + gap closing.
+// A merge of two 2^15 tiles has no 4-bit result: its entry is 0 and callers must rule it out (lut_guard).
+constexpr int kRowLutEntries = 65536;
+ML_HD uint16_t row_lut_entry(uint32_t idx) {
+    const uint32_t x = (idx & 0xFu) | ((idx & 0xF0u) << 4) | ((idx & 0xF00u) << 8) | ((idx & 0xF000u) << 12);
+    uint32_t mexp;
+    const uint32_t y = push_line(x, mexp);
+    if (y & 0xF0F0F0F0u) return 0;
+    return (uint16_t)((y & 0xFu) | ((y >> 4) & 0xF0u) | ((y >> 8) & 0xF00u) | ((y >> 12) & 0xF000u));
+}
+
+// move_board(in, action).board for boards whose lines are in the table's domain; lut[idx] = row_lut_entry(idx) for the
+// 65 536 line indices (in LDS on the device).
+// Measured and dropped (262 144 boards, tools/debug/sq_lut.sh): the low index byte XOR-ed with the high one so that the
+// small cell values of real play spread over the LDS banks (SQ_LDS_BANK_CONFLICT 47 -> 21 cycles per wave-step, kernel
+// 170 us either way: the look-up's round trip, not the LDS pipe, is what a wave waits for), and the next step's table
+// requests issued between the look-ups and their use (no change).
+template <class LutPtr>
+ML_HD Board move_board_lut(const Board &in, uint32_t action, LutPtr lut) {
+    const bool horizontal = (action & 2u) == 0;
+    const bool reverse = (action & 1u) != 0;
+    Board b = in;
+    if (horizontal) b = transpose(b);
+    const uint32_t a = reverse ? b.r[3] : b.r[0], bb = reverse ? b.r[2] : b.r[1];
+    const uint32_t c = reverse ? b.r[1] : b.r[2], d = reverse ? b.r[0] : b.r[3];
+    // byte j of n01 / n23 = the low / high byte of line j's index
+    const uint32_t n01 = a | (bb << 4), n23 = c | (d << 4);
+    const uint32_t r0 = lut[perm_b32(n23, n01, 0x0c0c0400u)];
+    const uint32_t r1 = lut[perm_b32(n23, n01, 0x0c0c0501u)];
+    const uint32_t r2 = lut[perm_b32(n23, n01, 0x0c0c0602u)];
+    const uint32_t r3 = lut[perm_b32(n23, n01, 0x0c0c0703u)];
+    const uint32_t r01 = r0 | (r1 << 16), r23 = r2 | (r3 << 16);
+    const uint32_t e = perm_b32(r23, r01, 0x06040200u); // byte j = cells 0, 1 of line j as nibbles
+    const uint32_t f = perm_b32(r23, r01, 0x07050301u); // byte j = cells 2, 3
+    const uint32_t o0 = e & 0x0F0F0F0Fu, o1 = (e >> 4) & 0x0F0F0F0Fu;
+    const uint32_t o2 = f & 0x0F0F0F0Fu, o3 = (f >> 4) & 0x0F0F0F0Fu;
+    b.r[0] = reverse ? o3 : o0;
+    b.r[1] = reverse ? o2 : o1;
+    b.r[2] = reverse ? o1 : o2;
+    b.r[3] = reverse ? o0 : o3;
+    if (horizontal) b = transpose(b);
+    return b;
+}
+
+// every tile <= 2^11 and at most 8 191 steps ahead: the tile sum (<= 16 * 2048 now, + 4 per step at most) stays below
+// 2^16, so no tile reaches 2^16 and no line leaves the table's domain (two 2^15 tiles would need a sum >= 2^16)
+constexpr int kRowLutMaxSteps = 8191;
+ML_HD bool lut_guard(const Board &b) {
+    return (((b.r[0] + 0x74747474u) | (b.r[1] + 0x74747474u) | (b.r[2] + 0x74747474u) | (b.r[3] + 0x74747474u)) &
+            0x80808080u) == 0u && ((b.r[0] | b.r[1] | b.r[2] | b.r[3]) & 0x80808080u) == 0u;
+}
+
 // ---- merged[16] bucket counters (the record's `merged` field) ---------------------------------
 // merged[num] += 1 for num in 1..15; num >= 16 is the reference's out-of-bounds write (H9) whose
 // target byte is rewritten by _compute_valid_actions before anything reads it, so it is dropped.
@@ -754,11 +811,29 @@ ML_HD int32_t score_potential(const Board &b, int32_t step) {
     }
     return sum;
 }
-// tiles <= 2^15, an integer score in [0, 2^21): with at most 65 536 steps the tile sum stays below 2^20 and the score
-// below 2^21 + 17 * 786 432 < 2^24
-ML_HD bool phi_guard(const Board &b, float score) {
+// sum of the tiles on the board (exponents <= 31)
+ML_HD uint32_t tile_sum(const Board &b) {
+    uint32_t sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum += (1u << ((b.r[q] >> (8 * j)) & 31u)) & ~1u; // an empty cell (1 << 0) adds nothing
+    }
+    return sum;
+}
+// When may a rollout of n_steps steps take its score from the board?  The identity above counts EVERY merge, but the
+// reference drops the reward of a merge of two 2^16 (or 2^17) tiles: `buckets[num] += 1` with num = 16 lands outside
+// merged[16] (H9) and reward_fn_normal never sees it.  So no 2^17 tile may appear during the rollout: a valid move adds
+// one spawned tile (<= 4) to the tile sum and merges keep it, hence tile_sum + 4 * n_steps < 2^17 rules it out (and with it
+// every exponent above 16).  Tiles <= 2^15 now and an integer score in [0, 2^21) keep every intermediate value an exact
+// integer below 2^24 (potential <= 13 * 2^17), as the float32 running sum of the reference (H8) holds them.
+// Round 2's guard only bounded the values (tiles <= 2^15, <= 65 536 steps) and was wrong for loaded states that reach two
+// 2^16 tiles inside the rollout (tests/test_gpu_plain_rollout.py::test_plain_large_pass_on_boards_outside_the_table_guard
+// found it); play from a deal never gets near (a 2^17 tile needs a tile sum of 131 072).
+ML_HD bool phi_guard(const Board &b, float score, int32_t n_steps) {
     const bool small = ((b.r[0] | b.r[1] | b.r[2] | b.r[3]) & 0xF0F0F0F0u) == 0u;
-    return small && score >= 0.0f && score < 2097152.0f && (float)(int32_t)score == score;
+    const bool no_dropped_reward = n_steps >= 0 && n_steps < 32768 && tile_sum(b) + 4u * (uint32_t)n_steps < 131072u;
+    return small && no_dropped_reward && score >= 0.0f && score < 2097152.0f && (float)(int32_t)score == score;
 }
 // step_pre_lazy without any reward arithmetic: the caller keeps the board and the action of the last VALID move
 // (`pv`, `pv_action`) and restores score (score_potential), reward and merged[] (one more move_board on `pv`) after its
@@ -770,6 +845,29 @@ ML_HD bool step_pre_lazy_pv(StepRegs &s, uint32_t action, Board &pv, uint32_t &p
     pv = prev;
     pv_action = action;
     s.board = mv.board;
+    s.step += 1;
+    return true;
+}
+
+// the two steps above with the move looked up (move_board_lut; callers establish lut_guard first)
+template <class LutPtr>
+ML_HD bool step_pre_lazy_pv_lut(StepRegs &s, uint32_t action, Board &pv, uint32_t &pv_action, LutPtr lut) {
+    const Board prev = s.board;
+    const Board nb = move_board_lut(prev, action & 3u, lut);
+    if (action >= 4u || !board_differs(nb, prev)) return false;
+    pv = prev;
+    pv_action = action;
+    s.board = nb;
+    s.step += 1;
+    return true;
+}
+template <class LutPtr>
+ML_HD bool step_pre_lite_pv_lut(StepRegs &s, uint32_t action, Board &pv, uint32_t &pv_action, LutPtr lut) {
+    const bool ok = action < 4u && ((s.valid >> (8u * (action & 3u))) & 0xFFu) != 0u;
+    if (!ok) return false;
+    pv = s.board;
+    pv_action = action;
+    s.board = move_board_lut(pv, action, lut);
     s.step += 1;
     return true;
 }

@@ -8,6 +8,7 @@
 // exactly 64 lanes x 16 B, one dwordx4 store per lane per board.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <algorithm>
 #include <atomic>
 #include <type_traits>
 #include <rocrand/rocrand_kernel.h>
@@ -58,8 +59,10 @@ struct ml2048_plain_launch {
     const uint4 *up_src;
     uint4 *up_dst;
     int64_t up_n16;
-    unsigned up_blocks;
+    unsigned up_blocks; // 0 = no chained upload, 1 = by an extra wave per workgroup, 2 = by each workgroup's first wave
     int64_t up_tab16;
+    const uint16_t *row_lut; // the 65 536 line look-ups of ml2048_row_lut_fill, or NULL: the arithmetic move
+    int board_waves;         // board-carrying waves per workgroup (the plain kernels' workgroup = one CU's share of the boards)
 };
 __attribute__((visibility("hidden"))) int ml2048_internal_launch_rollout_plain_ilp(int reward_kind, bool fast, bool inv_tables,
                                                                                    const ml2048_plain_launch &a);
@@ -87,6 +90,10 @@ int check_launch(const char *what) {
 }
 
 constexpr int kBlock = 256;      // threads per workgroup for the per-board kernels (4 waves)
+// The plain rollout kernels hold the 128 KiB line table in LDS, i.e. ONE workgroup per compute unit: the workgroup is
+// sized at launch to the CU's whole share of the boards, up to 16 waves (4 per SIMD).
+constexpr int kRollMaxBlock = 1024;
+constexpr int kRollMaxWaves = kRollMaxBlock / 64;
 // rollout steps whose re-deal flags are parked between flushes: in LDS (128 steps), or - ML2048_LONE_WAVE, the
 // small-M pass of the plain kernels - in a register pair, one step per lane (64 steps)
 #ifdef ML2048_LONE_WAVE
@@ -787,7 +794,7 @@ __global__ __launch_bounds__(kBlock) void k_digest(ml2048_state st, int64_t M, i
 // with one wave per SIMD every taken branch costs an instruction-buffer refill, and a dozen
 // "pointer is NULL, skip" branches per step were ~10 % of the kernel (SQ_WAIT_ANY, profiles/).
 template <int KIND, bool FAST, bool EXTRAS, bool INV>
-__global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, int64_t idx_base, int N,
+__global__ __launch_bounds__(EXTRAS ? kBlock : kRollMaxBlock) void k_rollout(ml2048_state st, int64_t M, int64_t idx_base, int N,
                                                     const uint8_t *__restrict__ perm_epochs,
                                                     const uint32_t *__restrict__ two_masks,
                                                     const int32_t *__restrict__ schedule, int n_epochs,
@@ -798,38 +805,81 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                                                     int32_t *__restrict__ last_reset, uint64_t spawn_seed,
                                                     uint64_t spawn_counter0, uint64_t thr, ml2048_traj traj,
                                                     const uint4 *__restrict__ up_src, uint4 *__restrict__ up_dst,
-                                                    int64_t up_n16, unsigned up_blocks, int64_t up_tab16) {
+                                                    int64_t up_n16, unsigned up_blocks, int64_t up_tab16,
+                                                    const uint16_t *__restrict__ row_lut, int board_waves) {
     // The re-deal flags (one 64-bit ballot per step) of up to kFlagChunk steps are parked so that the step loop holds
     // no global store (its acknowledgement would share the vmcnt queue with the prefetched loads): in LDS, or - the
     // pass for small M, where a lone wave per SIMD pays for every slot - in a VGPR pair, step q of the chunk in lane q,
     // written with v_writelane.  The LDS write shares lgkmcnt with the scalar loads of the schedule and its lane-0
     // store needs an exec-mask round trip: 3.7 us of the 95.7 us kernel at C2; the register form costs 1.6 us less
     // there and 1 % more at 1 M boards (two more VALU per step where other waves hid the LDS write anyway).
-#ifdef ML2048_LONE_WAVE
-    uint32_t park_lo = 0, park_hi = 0;
-    const unsigned long long live_lanes = __builtin_amdgcn_ballot_w64((int64_t)blockIdx.x * kBlock + threadIdx.x < M);
-#else
-    __shared__ unsigned long long flag_park[kBlock / 64][kFlagChunk];
-#endif
     // The schedule kernel of the NEXT rollout (csrc/devrng.hip) may share a CU with one of these
     // workgroups; the rollout is the critical path, so its waves win the issue arbitration.
     __builtin_amdgcn_s_setprio(1);
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave_in_wg = (int)(threadIdx.x >> 6);
+    // Workgroup shape.  EXTRAS: 256 threads = 4 board waves, as every per-board kernel.  Plain: `board_waves` board waves
+    // (+ one upload wave, up_blocks == 1), chosen at launch so that ONE workgroup carries a compute unit's whole share
+    // of the boards - the line table below takes 128 of the CU's 160 KiB of LDS, so workgroups do not share a CU.
+    const int bw = EXTRAS ? kBlock / 64 : board_waves;
+    const int64_t wave_global = (int64_t)blockIdx.x * bw + wave_in_wg;
+    const int64_t i = wave_global * 64 + lane;
+#ifndef ML2048_LONE_WAVE
+    __shared__ unsigned long long flag_park[EXTRAS ? kBlock / 64 : kRollMaxWaves][kFlagChunk];
+#endif
+    // The line table (board_ops.hpp move_board_lut): 65 536 x uint16 in LDS, copied from the caller's device buffer by
+    // the whole workgroup (16-byte units, eight requests in flight per thread).  Only in the large-M pass: with several
+    // waves per SIMD the ~85 VALU of the arithmetic move are what bounds the kernel and the LDS round trip of a look-up
+    // hides behind the other waves (262 144 boards: 189 -> 170 us); a lone wave per SIMD pays that round trip in full
+    // every step (C2: 68 -> 78 us, SQ_WAIT_ANY 63 -> 147 quad-cycles per wave-step), so the small-M passes keep the
+    // arithmetic move and no table (tools/debug/lut_ab.sh, sq_lut.sh).
+#ifdef ML2048_LONE_WAVE
+    constexpr bool HAS_LUT = false;
+#else
+    constexpr bool HAS_LUT = !EXTRAS;
+#endif
+    __shared__ uint16_t lut_s[HAS_LUT ? kRowLutEntries : 8];
+    if constexpr (!EXTRAS) {
+        if (HAS_LUT && row_lut) {
+            const uint4 *g = reinterpret_cast<const uint4 *>(row_lut);
+            uint4 *l = reinterpret_cast<uint4 *>(lut_s);
+            constexpr int kUnits = kRowLutEntries * 2 / 16, kInFlight = 8;
+            const int nthr = (int)blockDim.x;
+            for (int k0 = (int)threadIdx.x; k0 < kUnits; k0 += kInFlight * nthr) {
+                uint4 v[kInFlight];
+#pragma unroll
+                for (int u = 0; u < kInFlight; ++u)
+                    if (k0 + u * nthr < kUnits) v[u] = g[k0 + u * nthr];
+#pragma unroll
+                for (int u = 0; u < kInFlight; ++u)
+                    if (k0 + u * nthr < kUnits) l[k0 + u * nthr] = v[u];
+            }
+            __syncthreads();
+        }
+        // Chained upload: this launch also copies the NEXT rollout's packed schedule from device-accessible
+        // host memory into the other device buffer - ordered before the next launch by the stream itself,
+        // so the upload needs neither a copy stream nor an event (a cross-stream wait in front of every
+        // rollout kernel cost ~19 us of idle GPU, tools/debug/marker_cost.py).  The copy is done by one extra
+        // wave per workgroup (up_blocks == 1: it shares a SIMD with a board wave for the few microseconds of a PCIe
+        // read and is gone) or, where the workgroup already has its 16 waves, by each workgroup's first wave before
+        // it turns to its boards (up_blocks == 2; large M: the other waves of its SIMD fill the slots meanwhile).
+        // Either way no board wave sits behind a PCIe read in the in-order vmcnt queue during its step loop.
+        if (up_blocks != 0 && wave_in_wg == (up_blocks == 1 ? bw : 0)) {
+            for (int64_t j = (int64_t)blockIdx.x * 64 + lane; j < up_n16; j += (int64_t)gridDim.x * 64)
+                upload_unit(up_dst, up_src, j, up_tab16);
+        }
+        if (wave_in_wg >= bw || wave_global * 64 >= M) return; // the upload wave; a wave past the last board
+        // flag words past the last board's wave (flag_words is rounded up to four waves): nobody else writes them
+        if ((wave_global + 1) * 64 >= M)
+            for (int64_t w = wave_global + 1; w < flag_words; ++w)
+                for (int t = lane; t < N; t += 64) reset_flags[(int64_t)t * flag_words + w] = 0ull;
+    }
+#ifdef ML2048_LONE_WAVE
+    uint32_t park_lo = 0, park_hi = 0;
+    const unsigned long long live_lanes = __builtin_amdgcn_ballot_w64(i < M);
+#endif
     const bool live = i < M;
     const int64_t ii = live ? i : M - 1; // tail lanes shadow the last board (loads only, no stores)
-    const int lane = threadIdx.x & 63;
-    const int64_t wave_global = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
-    // Chained upload: this launch also copies the NEXT rollout's packed schedule from device-accessible
-    // host memory into the other device buffer - ordered before the next launch by the stream itself,
-    // so the upload needs neither a copy stream nor an event (a cross-stream wait in front of every
-    // rollout kernel cost ~19 us of idle GPU, tools/debug/marker_cost.py).  The copy is done by extra
-    // workgroups appended to the grid (up_blocks of them): they share CUs with the board workgroups and
-    // are gone after a few microseconds, so no board ever waits for a PCIe read.
-    if (up_blocks > 0 && blockIdx.x >= gridDim.x - up_blocks) {
-        const int64_t first = (int64_t)(blockIdx.x - (gridDim.x - up_blocks)) * kBlock + threadIdx.x;
-        for (int64_t j = first; j < up_n16; j += (int64_t)up_blocks * kBlock) upload_unit(up_dst, up_src, j, up_tab16);
-        return;
-    }
 
 #if defined(ML2048_LONE_WAVE) && (!defined(ML2048_SCHED_AHEAD) || ML2048_SCHED_AHEAD)
     // The lane-held schedule of a 64-step chunk (see run_steps): its entries are requested a chunk ahead - the first
@@ -948,15 +998,21 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
     // reward function for the others.  A wave with a board or a score outside the guard's range (never in play from a
     // deal) takes the eager loop.
     // The same holds with a maintained mask (masked sampling without optional outputs): `defer`.
-    const bool defer = !EXTRAS && N <= 65536 && __all(phi_guard(s.board, s.score) ? 1 : 0);
+    const bool defer = !EXTRAS && __all(phi_guard(s.board, s.score, N) ? 1 : 0);
     lazy = lazy && defer;
     int32_t phi_acc = 0; // score - potential, as of the game's start inside this rollout
     if (defer) phi_acc = (int32_t)s.score - score_potential(s.board, s.step);
     Board pv = s.board;      // the board the last valid move started from ...
     uint32_t pv_action = 4u; // ... and its action (4 = none since the deal / since the rollout began)
-    auto run_steps = [&](auto lazy_tag, auto defer_tag) {
+    // The loops without reward arithmetic keep nothing of a move but the board, so the move can be four look-ups in the
+    // LDS line table instead of ~85 VALU (board_ops.hpp move_board_lut) - for waves whose boards stay inside the
+    // table's domain for the whole rollout (lut_guard: tiles <= 2^11 now, at most 8 191 steps).
+    bool use_lut = false;
+    if constexpr (HAS_LUT) use_lut = defer && row_lut != nullptr && N <= kRowLutMaxSteps && __all(lut_guard(s.board) ? 1 : 0);
+    auto run_steps = [&](auto lazy_tag, auto defer_tag, auto lut_tag) {
         constexpr bool LAZY = decltype(lazy_tag)::value;
         constexpr bool DEFER = decltype(defer_tag)::value; // no reward arithmetic in the loop (always with LAZY)
+        constexpr bool LUT = decltype(lut_tag)::value;     // the move by table look-up (only with DEFER)
         // LAZY (always two bits per draw, sixteen draws per word): inside a chunk the groups of kStepUnroll steps start on
         // a multiple of kStepUnroll of the sampler's counter (`group_lead` single steps come first; the chunks themselves
         // start on multiples of kFlagChunk) - a new word can then only fall due at the first step of a group, and the
@@ -1069,7 +1125,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
 #ifdef ML2048_LONE_WAVE
                 write_lane64(park_lo, park_hi, dealt, t - t0);
 #else
-                if (lane == 0) flag_park[threadIdx.x >> 6][t - t0] = dealt;
+                if (lane == 0) flag_park[wave_in_wg][t - t0] = dealt;
 #endif
                 if (deal) {
                     clear_regs(s);
@@ -1127,8 +1183,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
                 // ---- step (game_numba.py:660-738)
                 prev_board = s.board;
                 if (!LAZY) prev_valid = s.valid;
-                if (LAZY    ? step_pre_lazy_pv(s, action, pv, pv_action)
-                    : DEFER ? step_pre_lite_pv(s, action, pv, pv_action)
+                if (LAZY    ? (LUT ? step_pre_lazy_pv_lut(s, action, pv, pv_action, lut_s) : step_pre_lazy_pv(s, action, pv, pv_action))
+                    : DEFER ? (LUT ? step_pre_lite_pv_lut(s, action, pv, pv_action, lut_s) : step_pre_lite_pv(s, action, pv, pv_action))
                             : step_pre_lite(s, action, KIND, mexp_first, mexp_second)) {
                     merged_stale = true;
                     uint32_t empties = 0;
@@ -1228,22 +1284,24 @@ __global__ __launch_bounds__(kBlock) void k_rollout(ml2048_state st, int64_t M, 
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             for (int q = lane; q < t1 - t0; q += 64)
-                reset_flags[(int64_t)(t0 + q) * flag_words + wave_global] = flag_park[threadIdx.x >> 6][q];
+                reset_flags[(int64_t)(t0 + q) * flag_words + wave_global] = flag_park[wave_in_wg][q];
 #endif
         }
     };
     if constexpr (EXTRAS) {
-        run_steps(std::false_type{}, std::false_type{});
+        run_steps(std::false_type{}, std::false_type{}, std::false_type{});
     } else {
         if (!defer) {
-            run_steps(std::false_type{}, std::false_type{});
+            run_steps(std::false_type{}, std::false_type{}, std::false_type{});
         } else {
             if (lazy) {
-                run_steps(std::true_type{}, std::true_type{});
+                if (HAS_LUT && use_lut) run_steps(std::true_type{}, std::true_type{}, std::bool_constant<HAS_LUT>{});
+                else run_steps(std::true_type{}, std::true_type{}, std::false_type{});
                 s.valid = valid_actions(s.board);
                 prev_valid = valid_actions(prev_board);
             } else {
-                run_steps(std::false_type{}, std::true_type{});
+                if (HAS_LUT && use_lut) run_steps(std::false_type{}, std::true_type{}, std::bool_constant<HAS_LUT>{});
+                else run_steps(std::false_type{}, std::true_type{}, std::false_type{});
             }
             s.score = (float)(phi_acc + score_potential(s.board, s.step));
             if (merged_stale) { // a deal or a valid move happened: the record shows the last valid move since the deal
@@ -1572,7 +1630,7 @@ int ML2048_ROLLOUT_PLAIN_TU(int reward_kind, bool fast, bool inv_tables, const m
                           a.idx_base, a.N, a.perm_epochs, a.two_masks, a.schedule, a.n_epochs, a.masked, a.act_seed,   \
                           a.act_counter0, (uint8_t *)nullptr, (uint64_t *)nullptr, a.reset_flags, a.flag_words,        \
                           a.last_reset, a.spawn_seed, a.spawn_counter0, a.two_threshold, traj, a.up_src, a.up_dst,     \
-                          a.up_n16, a.up_blocks, a.up_tab16)
+                          a.up_n16, a.up_blocks, a.up_tab16, a.row_lut, a.board_waves)
 #define ML_PLAIN_KIND(K)                 \
     if (fast) {                          \
         ML_PLAIN(K, true, false);        \
@@ -1776,6 +1834,7 @@ static thread_local ml2048_timer_impl *g_armed_timer = nullptr;
 // ml2048_rollout_chain_ids: the rollout's marker event rides on the kernel's own dispatch (its completion signal)
 // instead of a marker packet behind it - one-shot, consumed by the next launch_rollout of this thread
 static thread_local hipEvent_t g_attach_stop_event = nullptr;
+static thread_local const uint16_t *g_attach_row_lut = nullptr; // one-shot: the next rollout launch's line table
 static thread_local bool g_stop_event_attached = false;
 
 int ml2048_timer_create(void **timer) {
@@ -1838,9 +1897,24 @@ extern "C" {
 static int64_t plain_ilp_max_boards() {
     static const int64_t v = [] {
         const char *e = getenv("ML2048_PLAIN_ILP_MAX");
-        return e ? (int64_t)atoll(e) : (int64_t)196608; // up to three waves per SIMD (tools/debug/ilpmax_ab.sh)
+        // up to two waves per SIMD: from three on the large-M pass with its LDS line table wins (196 608 boards: 138
+        // vs 151 us; 131 072: 110 vs 108 us, tools/debug/ilpmax_lut.sh)
+        return e ? (int64_t)atoll(e) : (int64_t)131072;
     }();
     return v;
+}
+
+// compute units of the current device (the plain rollout sizes its workgroups to a CU's share of the boards)
+static int cu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
 }
 
 static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
@@ -1849,7 +1923,7 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
                           uint64_t *digests_out, uint64_t *reset_flags, int32_t *last_reset, uint64_t spawn_seed,
                           uint64_t spawn_counter0, double two_prob, const ml2048_traj *traj_or_null,
                           const void *up_src = nullptr, void *up_dst = nullptr, int64_t up_nbytes = 0,
-                          int64_t up_table_offset = -1, bool inv_tables = false) {
+                          int64_t up_table_offset = -1, bool inv_tables = false, const uint16_t *row_lut = nullptr) {
     ml2048_traj traj = {};
     if (up_table_offset < 0) up_table_offset = up_nbytes; // no table units: a plain copy
     if (up_table_offset > up_nbytes || (up_table_offset < up_nbytes && (up_table_offset % 16 || (up_nbytes - up_table_offset) % 16)))
@@ -1860,7 +1934,9 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
     }
     const int64_t up_n16 = (up_nbytes + 15) / 16;
     const int64_t up_tab16 = up_table_offset >= up_nbytes ? up_n16 : up_table_offset / 16;
-    const unsigned up_blocks = up_n16 > 0 ? (unsigned)(cdiv(up_n16, kBlock) < 64 ? cdiv(up_n16, kBlock) : 64) : 0u;
+    if (!row_lut) row_lut = g_attach_row_lut;
+    g_attach_row_lut = nullptr;
+    if ((uintptr_t)row_lut % 16) return fail(ML2048_E_ALIGN, "row_lut must be 16-byte aligned");
     if (traj_or_null) {
         traj = *traj_or_null;
         if (((uintptr_t)traj.state | (uintptr_t)traj.next_state) % 16)
@@ -1869,7 +1945,7 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
              (uintptr_t)traj.step | (uintptr_t)traj.action_log_prob) % 4)
             return fail(ML2048_E_ALIGN, "4-byte trajectory outputs must be 4-byte aligned");
     }
-    const dim3 grid((unsigned)cdiv(M, kBlock) + up_blocks), block(kBlock); // board workgroups, then the upload's
+    const dim3 grid((unsigned)cdiv(M, kBlock)), block(kBlock); // the EXTRAS instantiations: 4 board waves per workgroup
     const int64_t W = ml2048_rollout_flag_words(M);
     const uint64_t thr = two_threshold(two_prob);
     const bool extras = actions_out || digests_out || traj_or_null;
@@ -1884,15 +1960,23 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
     }
     g_attach_stop_event = nullptr;
     if (inv_tables && (fast || extras)) return fail(ML2048_E_UNSUPPORTED, "expanded tables: plain table-mode rollouts only");
+    if (extras && up_n16 > 0) return fail(ML2048_E_UNSUPPORTED, "chained upload: plain rollouts only");
     if (!extras) { // the plain instantiations live in their own compilation passes (see ml2048_plain_launch)
+        // one workgroup = one compute unit's share of the boards (the LDS line table leaves room for one workgroup per
+        // CU): up to 16 board waves, plus the upload wave where there is room for it
+        const int64_t waves = cdiv(M, 64);
+        const int bw = (int)std::min<int64_t>(kRollMaxWaves, std::max<int64_t>(1, cdiv(waves, cu_count())));
+        const unsigned up_mode = up_n16 > 0 ? (bw < kRollMaxWaves ? 1u : 2u) : 0u;
         ml2048_plain_launch a;
-        a.grid = grid, a.block = block, a.stream = s, a.ev_start = ev_start, a.ev_stop = ev_stop;
+        a.grid = dim3((unsigned)cdiv(waves, bw)), a.block = dim3(64u * (unsigned)(bw + (up_mode == 1u ? 1 : 0)));
+        a.stream = s, a.ev_start = ev_start, a.ev_stop = ev_stop;
+        a.row_lut = row_lut, a.board_waves = bw;
         a.st = *st, a.M = M, a.idx_base = idx_base, a.N = N;
         a.perm_epochs = perm_epochs, a.two_masks = two_masks, a.schedule = schedule, a.n_epochs = n_epochs;
         a.masked = masked, a.act_seed = act_seed, a.act_counter0 = act_counter0;
         a.reset_flags = reset_flags, a.flag_words = W, a.last_reset = last_reset;
         a.spawn_seed = spawn_seed, a.spawn_counter0 = spawn_counter0, a.two_threshold = thr;
-        a.up_src = (const uint4 *)up_src, a.up_dst = (uint4 *)up_dst, a.up_n16 = up_n16, a.up_blocks = up_blocks, a.up_tab16 = up_tab16;
+        a.up_src = (const uint4 *)up_src, a.up_dst = (uint4 *)up_dst, a.up_n16 = up_n16, a.up_blocks = up_mode, a.up_tab16 = up_tab16;
         const bool small = M <= plain_ilp_max_boards();
         if (small ? (!fast && !masked ? ml2048_internal_launch_rollout_plain_lone(reward_kind, fast, inv_tables, a)
                                       : ml2048_internal_launch_rollout_plain_ilp(reward_kind, fast, inv_tables, a))
@@ -1904,7 +1988,8 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
     hipExtLaunchKernelGGL((k_rollout<K, F, true, false>), grid, block, 0, s, ev_start, ev_stop, 0, *st, M, idx_base, N, perm_epochs, two_masks, \
                        schedule, n_epochs, masked, act_seed, act_counter0, actions_out, digests_out,         \
                        reset_flags, W,                                                                       \
-                       last_reset, spawn_seed, spawn_counter0, thr, traj, (const uint4 *)up_src, (uint4 *)up_dst, up_n16, up_blocks, up_tab16)
+                       last_reset, spawn_seed, spawn_counter0, thr, traj, (const uint4 *)nullptr, (uint4 *)nullptr, (int64_t)0, 0u, (int64_t)0, \
+                       (const uint16_t *)nullptr, kBlock / 64)
 #define ML_KIND(F)                                                                   \
     switch (reward_kind) {                                                           \
     case ML2048_REWARD_NORMAL: ML_LAUNCH2(REWARD_NORMAL, F); break;                  \
@@ -2061,6 +2146,23 @@ int ml2048_rollout_attach_event(void *event) {
 }
 
 int ml2048_rollout_event_attached(void) { return g_stop_event_attached ? 1 : 0; }
+
+// ---- the line table of the plain rollout kernels (board_ops.hpp row_lut_entry / move_board_lut) ----------------------
+__global__ __launch_bounds__(kBlock) void k_fill_row_lut(uint16_t *__restrict__ lut) {
+    const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx < (uint32_t)kRowLutEntries) lut[idx] = row_lut_entry(idx);
+}
+
+int ml2048_row_lut_fill(void *stream, void *lut) {
+    if (!lut || (uintptr_t)lut % 16) return fail(ML2048_E_ALIGN, "lut must be a 16-byte aligned device buffer of ML2048_ROW_LUT_BYTES");
+    hipLaunchKernelGGL(k_fill_row_lut, dim3(kRowLutEntries / kBlock), dim3(kBlock), 0, (hipStream_t)stream, (uint16_t *)lut);
+    return check_launch("ml2048_row_lut_fill");
+}
+
+int ml2048_rollout_attach_row_lut(const void *lut) {
+    g_attach_row_lut = (const uint16_t *)lut;
+    return 0;
+}
 
 int ml2048_rollout_chain_ids(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
                              const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,

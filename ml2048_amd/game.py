@@ -206,6 +206,25 @@ class _RolloutBuffers(collections.abc.Mapping):
         return len(self._KEYS)
 
 
+_ROW_LUTS: dict = {}  # device index -> the line table of the plain rollout kernels (constant data, 128 KiB)
+
+
+def _row_lut(L, device: torch.device) -> int:
+    """Device pointer of this device's line table (ml2048_row_lut_fill), built on first use.  ML2048_ROW_LUT=0 makes the
+    plain rollouts compute the move arithmetically instead (A/B; same results)."""
+    if os.environ.get("ML2048_ROW_LUT", "1") == "0":
+        return 0
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    t = _ROW_LUTS.get(key)
+    if t is None:
+        with torch.cuda.device(device):
+            t = torch.empty((131072,), dtype=torch.uint8, device=device)
+            _lib.check(L.ml2048_row_lut_fill(torch.cuda.current_stream(device).cuda_stream, t.data_ptr()), "row_lut_fill")
+            torch.cuda.current_stream(device).synchronize()  # any stream may read it from now on
+        _ROW_LUTS[key] = t
+    return t.data_ptr()
+
+
 class VecGame:
     """Vectorized 2048 environment on one MI355X (see module docstring)."""
 
@@ -260,6 +279,7 @@ class VecGame:
         self._spin_i = 0
         self._roll_ev = None        # ring of per-rollout events (ONE per rollout: the kernel's own completion event)
         self._plain_layouts = {}    # (M, N) -> offsets inside a plain rollout's one device allocation
+        self._lut_ptr = _row_lut(self._L, self.device)  # the plain rollout kernels' line table (0: arithmetic move)
         self._roll_i = 0
         self._sdev = [None, None]   # device-side packed schedules (the resident one and the next one)
         self._sdev_i = 0
@@ -361,6 +381,8 @@ class VecGame:
                 scratch = None
             if kernel_timer is not None:
                 _lib.check(L.ml2048_timer_arm(kernel_timer), "timer_arm")
+            if self._lut_ptr:
+                L.ml2048_rollout_attach_row_lut(self._lut_ptr)
             _lib.check(L.ml2048_rollout_chain_ids(
                 main, M, self._idx_base, self._st(), N, packed_ptr + o_tab, packed_ptr + o_mask, E, packed_ptr,
                 self._reward_kind, int(masked), int(act_seed), int(act_counter), base, base + o_last,
@@ -1190,6 +1212,8 @@ class VecGame:
                 roll_ev = self._next_roll_event()
                 if kernel_events is None:  # (markers around the kernel are wanted: then this one is a marker too)
                     _lib.check(L.ml2048_rollout_attach_event(roll_ev.h), "rollout_attach_event")
+            if self._lut_ptr and trajectory is None and a_ptr is None and d_ptr is None:
+                L.ml2048_rollout_attach_row_lut(self._lut_ptr)
             if trajectory is not None:
                 if fast or record_actions or digests:
                     raise ValueError("trajectory= is for table spawn mode, without record_actions/digests")

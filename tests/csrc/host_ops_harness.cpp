@@ -86,6 +86,38 @@ int64_t h_move_forms_check(const uint8_t *boards, int64_t n) {
     return bad;
 }
 
+// the move by table look-up (move_board_lut over the 65 536 entries of row_lut_entry) against move_board, on boards
+// inside the table's domain (exponents <= 15, no merge of two 2^15 tiles); boards outside it are skipped and counted
+// in *skipped.  Also checks lut_guard: a board it accepts must be in the domain for every direction.
+int64_t h_move_lut_check(const uint8_t *boards, int64_t n, int64_t *skipped) {
+    static uint16_t lut[kRowLutEntries];
+    static bool filled = false;
+    if (!filled) {
+        for (uint32_t i = 0; i < (uint32_t)kRowLutEntries; ++i) lut[i] = row_lut_entry(i);
+        filled = true;
+    }
+    int64_t bad = 0, skip = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        Board b;
+        memcpy(b.r, boards + 16 * i, 16);
+        const bool guarded = lut_guard(b);
+        for (uint32_t a = 0; a < 4; ++a) {
+            const MoveResult x = move_board(b, a);
+            const bool in_domain = ((b.r[0] | b.r[1] | b.r[2] | b.r[3]) & 0xF0F0F0F0u) == 0u &&
+                                   ((x.board.r[0] | x.board.r[1] | x.board.r[2] | x.board.r[3]) & 0xF0F0F0F0u) == 0u;
+            if (!in_domain) {
+                if (guarded) ++bad;
+                ++skip;
+                continue;
+            }
+            const Board y = move_board_lut(b, a, lut);
+            if (memcmp(x.board.r, y.r, 16) != 0) ++bad;
+        }
+    }
+    *skipped = skip;
+    return bad;
+}
+
 // stable compaction by position masks (compact_cells) == the six-step bubble it replaced, on n x 4 cell words
 int64_t h_compact_check(const uint32_t *words, int64_t n) {
     int64_t bad = 0;
@@ -164,13 +196,13 @@ void h_merged_value_sum(const uint32_t *words, int64_t n, uint32_t *out) {
 }
 
 // score_potential / phi_guard on n boards (16 bytes each)
-void h_score_potential(const uint8_t *boards, const int32_t *step, const float *score, int64_t n, int32_t *pot,
-                       uint8_t *guard) {
+void h_score_potential(const uint8_t *boards, const int32_t *step, const float *score, int64_t n, int32_t n_steps,
+                       int32_t *pot, uint8_t *guard) {
     for (int64_t i = 0; i < n; ++i) {
         ml2048::Board b;
         memcpy(b.r, boards + 16 * i, 16);
         pot[i] = ml2048::score_potential(b, step[i]);
-        guard[i] = ml2048::phi_guard(b, score[i]) ? 1 : 0;
+        guard[i] = ml2048::phi_guard(b, score[i], n_steps) ? 1 : 0;
     }
 }
 

@@ -98,8 +98,9 @@ def test_plain_c2_twice_back_to_back(amd, oracle):
 
 @pytest.mark.parametrize("M,lengths,reward,counter0", [
     (65536, [127, 65, 200], "improved", 13),   # remainder loop of the 8-step unroll; 64-step flag chunk edges
-    (196608, [128, 64], "rank", 0),            # largest M of the small-M passes (three waves per SIMD)
-    (196609, [128, 65], "maxcell", 77),        # smallest M of the large-M pass, ragged tail wave
+    (131072, [128, 64], "rank", 0),            # largest M of the small-M passes (two waves per SIMD)
+    (131073, [128, 65], "maxcell", 77),        # smallest M of the large-M pass (LDS line table), ragged tail wave
+    (196609, [65, 128], "improved", 40),       # 13 board waves per workgroup, the last workgroup partly past the boards
     (262144, [128, 128], "normal", 3),         # C4's per-GPU shard / C3's size
     (1000, [200, 65, 1], "improved", 31),      # ragged small M
     (63, [130], "rank", 5),
@@ -173,6 +174,44 @@ def test_plain_masked(amd, oracle, M, lengths, reward):
 ])
 def test_plain_rocrand_spawn(amd, oracle, M, lengths, masked):
     _run(amd, oracle, M, lengths, "improved", None, 11, masked=masked, spawn="rocrand")
+
+
+# ---- the large-M pass moves boards by LDS table look-up (board_ops.hpp move_board_lut) -----------------------------
+def test_plain_large_pass_without_the_line_table(amd, oracle, monkeypatch):
+    """ML2048_ROW_LUT=0: no table is handed to the launch and the large-M pass moves boards arithmetically (what it also
+    does by itself for waves outside the table's guard) - same results."""
+    monkeypatch.setenv("ML2048_ROW_LUT", "0")
+    _run(amd, oracle, 262144, [128, 65], "normal", "host-async", 7, ids="deferred")
+    _run(amd, oracle, 196608, [65], "rank", "host-async", 2, masked=True)
+
+
+def test_plain_large_pass_on_boards_outside_the_table_guard(amd, oracle):
+    """Tiles above 2^11 (the table's guard: lut_guard) loaded into some boards of a large-M env: those waves take the
+    arithmetic move, the others the look-ups; tiles 2^12 ... 2^15 merge and move exactly as the oracle's."""
+    M, N = 139264, 96                              # 2 176 waves: 9 per workgroup, large-M pass
+    env = amd.VecGame(M, "improved", schedule="host-async")
+    ref = oracle.OracleVecGame(M, "improved")
+    env.reset(23)
+    ref.reset(23)
+    env.prepare()
+    ref.prepare()
+    d = ref._data
+    rng = np.random.default_rng(2)
+    for idx in rng.choice(M, size=600, replace=False):   # ~600 of the 2 176 waves get one board with big tiles
+        cells = rng.choice(16, size=4, replace=False)
+        d["board"][idx, cells] = rng.integers(12, 16, size=4)
+        if rng.random() < 0.5:                            # two equal big tiles side by side: they merge on the first move
+            d["board"][idx, 0] = d["board"][idx, 1] = rng.integers(12, 15)
+        d["valid_actions"][idx] = oracle.compute_valid_actions(d["board"][idx])[0]
+    env.load_records(d)
+    env.rollout(N, masked=False, act_seed=ACT_SEED, act_counter=3)
+    for t in range(N):
+        ref.prepare()
+        a, _ = oracle.sample_actions(ref._data["valid_actions"], ACT_SEED, 3 + t, masked=False)
+        ref.step(a)
+    _assert_same(env, ref, "boards outside the table guard")
+    assert env._game_count == ref._game_count
+    assert int(ref._data["board"].max()) >= 13           # the big tiles were really in play
 
 
 # ---- the lazy loop's score comes from the board (board_ops.hpp score_potential); states outside its guard -----------

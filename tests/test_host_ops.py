@@ -36,6 +36,8 @@ def H():
     L.h_compact_check.restype = i64
     L.h_move_forms_check.argtypes = [vp, i64]
     L.h_move_forms_check.restype = i64
+    L.h_move_lut_check.argtypes = [vp, i64, vp]
+    L.h_move_lut_check.restype = i64
     L.h_lazy_mask_check.argtypes = [vp, i64]
     L.h_lazy_mask_check.restype = i64
     L.h_step.argtypes = [vp, i64, i64, vp, vp, vp, i32, dbl, i64, vp, vp]
@@ -132,7 +134,7 @@ def test_score_is_a_function_of_board_and_step(H, oracle):
     arithmetic (reward_fn_normal accumulates into score whatever reward_fn is, game_numba.py:729-731).  Checked move
     by move on the reference-derived oracle, with invalid moves (H3) and both 2/4 probabilities; and the guard that
     keeps every intermediate sum an exact float32 integer."""
-    H.h_score_potential.argtypes = [C.c_void_p] * 3 + [C.c_int64] + [C.c_void_p] * 2
+    H.h_score_potential.argtypes = [C.c_void_p] * 3 + [C.c_int64, C.c_int32] + [C.c_void_p] * 2
     H.h_score_potential.restype = None
     games = 0
     for two_prob, kind in ((0.8, "improved"), (0.3, "normal")):
@@ -152,7 +154,7 @@ def test_score_is_a_function_of_board_and_step(H, oracle):
                 board = np.ascontiguousarray(d["board"])
                 step = np.ascontiguousarray(d["step"])
                 score = np.ascontiguousarray(d["score"])
-                H.h_score_potential(_p(board), _p(step), _p(score), M, _p(pot), _p(guard))
+                H.h_score_potential(_p(board), _p(step), _p(score), M, 128, _p(pot), _p(guard))
                 assert np.array_equal(pot.astype(np.float32), score), (two_prob, t, phase)
                 assert guard.all()
         games += env._game_count
@@ -164,8 +166,28 @@ def test_score_is_a_function_of_board_and_step(H, oracle):
     steps = np.zeros(5, np.int32)
     pot = np.zeros(5, np.int32)
     guard = np.zeros(5, np.uint8)
-    H.h_score_potential(_p(boards), _p(steps), _p(scores), 5, _p(pot), _p(guard))
+    H.h_score_potential(_p(boards), _p(steps), _p(scores), 5, 128, _p(pot), _p(guard))
     assert guard.tolist() == [0, 0, 0, 0, 1]
+    # ... and so is every rollout in which two 2^16 tiles could meet: the reference drops that merge's reward (H9: bucket
+    # 16 is outside merged[16]) while the identity would count it.  A 2^17 tile needs a tile sum of 2^17: the guard asks
+    # for tile_sum + 4 * steps < 2^17.
+    boards = np.zeros((4, 16), np.uint8)
+    boards[0, :4] = 15                              # tile sum 131 072 already
+    boards[1, :3] = 15                              # 98 304: fine for 128 steps ...
+    boards[2, :3] = 15                              # ... not for 8 192 (98 304 + 32 768)
+    boards[3, :2] = 1                               # a fresh deal: up to 32 766 steps
+    scores = np.zeros(4, np.float32)
+    steps = np.zeros(4, np.int32)
+    pot = np.zeros(4, np.int32)
+    guard = np.zeros(4, np.uint8)
+    H.h_score_potential(_p(boards), _p(steps), _p(scores), 4, 128, _p(pot), _p(guard))
+    assert guard.tolist() == [0, 1, 1, 1]
+    H.h_score_potential(_p(boards), _p(steps), _p(scores), 4, 8192, _p(pot), _p(guard))
+    assert guard.tolist() == [0, 0, 0, 1]
+    H.h_score_potential(_p(boards), _p(steps), _p(scores), 4, 32766, _p(pot), _p(guard))
+    assert guard.tolist() == [0, 0, 0, 1]           # 4 + 4 * 32 766 = 131 068
+    H.h_score_potential(_p(boards), _p(steps), _p(scores), 4, 32767, _p(pot), _p(guard))
+    assert guard.tolist() == [0, 0, 0, 0]           # 4 + 4 * 32 767 = 2^17
 
 
 def test_valid_empties_maxcell_vs_oracle(H, oracle):
@@ -201,6 +223,28 @@ def test_move_all_lines_at_once_equals_line_by_line(H):
     dense = rng.integers(1, 4, size=(100000, 16)).astype(np.uint8)
     allb = np.ascontiguousarray(np.concatenate([boards.reshape(-1, 16), cols.reshape(-1, 16), sparse, dense]))
     assert H.h_move_forms_check(_p(allb), allb.shape[0]) == 0
+
+
+def test_move_by_table_lookup_equals_the_arithmetic_move(H):
+    """move_board_lut (four 16-bit line look-ups in the 65 536-entry table of _push_row results) == move_board for
+    every one of the 16^4 lines the table covers, placed in each line position of a board (all four directions), and
+    for random boards; boards outside the table's domain (a tile above 2^15, two 2^15 tiles merging) are skipped by
+    the harness and must be refused by lut_guard."""
+    import itertools
+
+    lines = np.array(list(itertools.product(range(16), repeat=4)), dtype=np.uint8)   # 65536 x 4
+    rng = np.random.default_rng(5)
+    boards = rng.integers(0, 16, size=(lines.shape[0], 4, 4)).astype(np.uint8)
+    boards[np.arange(lines.shape[0]), np.arange(lines.shape[0]) % 4, :] = lines       # as a row
+    cols = boards.copy().transpose(0, 2, 1).copy()                                      # and as a column
+    sparse = _random_boards(rng, 100000)                                                # exponents up to 17: some skipped
+    play = rng.integers(0, 12, size=(200000, 16)).astype(np.uint8)                      # what lut_guard accepts
+    play[rng.random(play.shape) < 0.4] = 0
+    dense = rng.integers(1, 4, size=(100000, 16)).astype(np.uint8)
+    allb = np.ascontiguousarray(np.concatenate([boards.reshape(-1, 16), cols.reshape(-1, 16), sparse, play, dense]))
+    skipped = np.zeros(1, np.int64)
+    assert H.h_move_lut_check(_p(allb), allb.shape[0], _p(skipped)) == 0
+    assert 0 < skipped[0] < allb.shape[0]          # the 2^15 + 2^15 lines and the boards above 2^15 were there
 
 
 def test_compaction_by_position_masks_equals_the_bubble(H):
