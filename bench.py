@@ -87,6 +87,11 @@ def parse():
                          "host-async (pipelined native producer threads drawing ahead), device (csrc/devrng2.hip: no host "
                          "threads; opt-in); auto (default) = host-async sized to this rank's CPU share "
                          "(ml2048_amd.shard.host_thread_plan)")
+    ap.add_argument("--min-warmup-ms", type=float, default=30.0,
+                    help="the W warm-up steps are repeated until at least this much time has passed: a bench step here is "
+                         "~0.07 ms, and the GPU needs ~3 ms of work after an idle stretch to reach its loaded clocks (with "
+                         "W = 5 the timed region ran 5 %% slower kernels than a long run: tools/debug/warm_ab.sh); "
+                         "0 = exactly W steps.  The line reports the count as warmup_steps_run")
     ap.add_argument("--prefetch", type=int, default=0,
                     help="draw the next rollout's host schedule on a worker thread (synchronous host schedule only)")
     return ap.parse_args()
@@ -176,6 +181,13 @@ def _inst_table():
         return {}
 
 
+def _json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return {}
+
+
 def _traffic(key: str):
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
@@ -209,10 +221,27 @@ def rollout_roofline(M: int, N: int, avg_ms: float, masked: bool, traj: bool, sp
         ach = valu * waves * N / (avg_ms * 1e-3) / 1e9
         r.update({"achieved": ach, "frac": ach / VALU_PEAK_GINST, "insts_per_wave_step": valu,
                   "insts_source": ent["source"], "insts_measured_at": ent.get("measured_at")})
-        if ent.get("all_per_wave_step") and waves <= N_SIMD:
-            # one wave per SIMD (or fewer): every instruction of the lone wave, of any type, takes an issue slot of 4 cycles
+        costs = _json("valu_issue_costs.json")  # tools/microbench/valu_rate.hip on this chip
+        if ent.get("all_per_wave_step") and waves <= N_SIMD and costs.get("lone_wave_cycles_per_inst"):
+            # one wave per SIMD (or fewer): every instruction of the lone wave, of any type, takes one issue slot - measured
+            # at ~5 cycles per instruction (the guide's 4 is the FP32 FMA's; v_cmp and v_readlane take ~8.5).  The share
+            # of the kernel's time that the wave spends issuing at that cadence:
+            cyc = costs["lone_wave_cycles_per_inst"]
             r["lone_wave_frac"] = ent["all_per_wave_step"] * waves * N / (avg_ms * 1e-3) / 1e9 / \
-                (min(waves, N_SIMD) * CLOCK_GHZ / 4.0)
+                (min(waves, N_SIMD) * CLOCK_GHZ / cyc)
+            r["lone_wave_cycles_per_inst"] = cyc
+            r["lone_wave_note"] = ("all instructions per wave-step x the measured issue cadence of a wave alone on its SIMD "
+                                   f"({cyc} cycles, {costs.get('source')}) / the step's duration at {CLOCK_GHZ} GHz")
+        mix = _json("valu_mix.json").get(f"k_rollout:{variant}:{pass_}")
+        if mix and waves > N_SIMD and costs.get("busy_simd_ns_full_rate"):
+            # several waves per SIMD: the SIMD's vector pipe is the shared resource; an instruction of this loop costs it
+            # mean_cost_vs_full_rate x the measured full-rate cost (half of the mix - v_perm_b32, v_cndmask_b32, v_dot4,
+            # three-operand VOP3 - issues at half rate).  Share of the step that pipe is busy:
+            per_inst_ns = mix["mean_cost_vs_full_rate"] * costs["busy_simd_ns_full_rate"]
+            r["valu_pipe_busy_frac"] = valu * (waves / N_SIMD) * per_inst_ns * 1e-9 / (avg_ms * 1e-3 / N)
+            r["valu_pipe_note"] = (f"{valu} vector instructions per wave-step x {waves / N_SIMD:.2f} waves per SIMD x "
+                                   f"{per_inst_ns:.3f} ns per instruction of this loop's mix on a busy SIMD "
+                                   f"(profiles/valu_mix.json, {costs.get('source')}) / the step's duration")
         assert r["frac"] <= 1.0, r
     else:
         r.update({"achieved": None, "frac": None, "insts_per_wave_step": None,
@@ -291,6 +320,7 @@ def main():
     masked = bool(args.masked) if args.masked is not None else args.mode == "obs"
 
     warm_timers = []  # timers of warm-up launches: kept alive until the run ends
+    warm_run = [0]    # warm-up steps the last measure() really ran (W, extended to --min-warmup-ms)
 
     def new_timer():
         tm = C.c_void_p()
@@ -312,23 +342,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def measure(step_fn, k, w):
-        """w untimed + k timed bench steps, barrier + synchronize on both sides, max over ranks."""
+    def measure(step_fn, k, w, finish=None):
+        """w untimed + k timed bench steps, barrier + synchronize on both sides, max over ranks.  `finish` (fused modes:
+        VecGame.join_ids) issues whatever the steps deferred - the ordered game-id scan of the LAST rollout, which no later
+        rollout() call is there to issue - so that it runs, and is waited for, inside the region it belongs to."""
         # Everything alive now is set-up that lives as long as the run: collect once and move it out of the cyclic
         # collector's sight.  A full collection with torch imported takes ~40 ms (tools/debug/hiccup_trace.py: one per
         # run, around the 750th rollout) - 500 rollouts' worth of a launch thread that has to stay ahead of a 70 us
         # kernel; after the freeze a collection only walks what the loop itself allocated.
         gc.collect()
         gc.freeze()
+        t_warm = time.perf_counter()
         for j in range(w):
             # one warm-up launch carries the kernel timer: whatever the first timed dispatch of a process sets up in the
             # runtime happens here, not inside the timed region (its time is not a sample)
             step_fn("warm" if j == 0 else False)
+        warm_run[0] = w
+        while w > 0 and (time.perf_counter() - t_warm) * 1e3 < args.min_warmup_ms:  # see --min-warmup-ms
+            step_fn(False)
+            warm_run[0] += 1
+        if finish is not None:
+            finish()
         barrier()
         every = args.event_every if args.event_every > 0 else max(8, k // 32)
         t0 = time.perf_counter()
         for i in range(k):
-            step_fn(i % every == every // 2)  # (not the window's first launch: it starts on an idle GPU)
+            step_fn(i % every == min(every // 2, k - 1))  # (not the window's first launch: it starts on an idle GPU)
+        if finish is not None:
+            finish()
         barrier()
         return max_over_ranks(time.perf_counter() - t0, dist)
 
@@ -397,7 +438,8 @@ def main():
         step_fn, timers, env = make_stepwise(M, N, masked, args.mode == "obs")
     else:
         step_fn, timers, env = make_stepwise3(M, N, masked)
-    dt = measure(step_fn, K, W)
+    dt = measure(step_fn, K, W, finish=env.join_ids)
+    warmup_steps_run = warm_run[0]
     value = world * M * N * K / dt
     avg_ms = timers_avg_ms(timers)
 
@@ -413,7 +455,7 @@ def main():
         saved_every = args.event_every
         # (1) the same C2 workload, one launch per env step (what a policy-driven RL loop uses)
         sfn, stm, _e = make_stepwise(M, N, masked, False, seed_off=100)
-        d1 = measure(sfn, 20, 3)
+        d1 = measure(sfn, 20, 3, finish=_e.join_ids)
         ms1 = timers_avg_ms(stm)
         extras["stepwise"] = {"value": M * N * 20 / d1, "unit": "board-steps/s", "us_per_env_step": d1 / (N * 20) * 1e6,
                               "workload": f"M={M} x N={N}, one ml2048_step_prepare launch per env step (step + re-deal + "
@@ -422,7 +464,7 @@ def main():
         del sfn, _e
         # (2) C3 = BASELINE.json configs[2]: M=262144, masked sampling + one-hot (M,16,4,4) f32 observation per env step
         sfn, stm, _e = make_stepwise(262144, N, True, True, seed_off=200)
-        d1 = measure(sfn, 8, 2)
+        d1 = measure(sfn, 8, 2, finish=_e.join_ids)
         ms1 = timers_avg_ms(stm)
         extras["c3_obs"] = {"value": 262144 * N * 8 / d1, "unit": "board-steps/s", "us_per_env_step": d1 / (N * 8) * 1e6,
                             "workload": f"C3: M=262144 x N={N}, per env step ONE launch = step + re-deal + masked-uniform "
@@ -432,7 +474,7 @@ def main():
         # (3) the fused rollout at C4's per-GPU shard size (M=262144: the large-M pass of the kernel)
         args.event_every = 4
         sfn, stm, _e = make_fused(262144, N, masked, "fused", args.schedule, seed_off=300)
-        d1 = measure(sfn, 120, 20)
+        d1 = measure(sfn, 120, 20, finish=_e.join_ids)
         ms1 = timers_avg_ms(stm)
         extras["fused_262144"] = {"value": 262144 * N * 120 / d1, "unit": "board-steps/s", "ms_per_step": d1 / 120 * 1e3,
                                   "workload": f"M=262144 (BASELINE config 4's per-GPU shard) x N={N}, fused rollout",
@@ -443,7 +485,7 @@ def main():
         # bit-exact with the oracle's counter-based spawn, NOT with numba)
         args.event_every = 8
         sfn, stm, _e = make_fused(M, N, masked, "fused", args.schedule, seed_off=400, spawn="rocrand")
-        d1 = measure(sfn, 200, 20)
+        d1 = measure(sfn, 200, 20, finish=_e.join_ids)
         ms1 = timers_avg_ms(stm)
         extras["rocrand_spawn_mode"] = {"value": M * N * 200 / d1, "unit": "board-steps/s", "ms_per_step": d1 / 200 * 1e3,
                                         "roofline": rollout_roofline(M, N, ms1, masked, False, "rocrand"),
@@ -474,6 +516,7 @@ def main():
         line = {
             "metric": "env board-steps/sec (M boards x N steps), bit-exact vs game_numba semantics",
             "value": value, "unit": "board-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "warmup_steps_run": warmup_steps_run,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{tag}M={M} boards/GPU x N={N} random-action env steps per bench step "
@@ -484,9 +527,11 @@ def main():
                        "per_rank": per_rank, "id_scan": args.ids,
                        "spawn": "table (bit-exact with the reference's PCG64 tables)" if args.spawn == "table" else
                                 "rocrand (rocRAND Philox spawn: the same game statistically, not bit-exact with numba)",
-                       "timing": "W warm-up steps (the first one carries a kernel timer, so the runtime's one-off set-up for "
-                                 "timed dispatches is not inside the timed region), barrier + synchronize, exactly K steps, "
-                                 "barrier + synchronize; gc.collect() + gc.freeze() before the warm-up; the kernel timer "
+                       "timing": "W warm-up steps, repeated until --min-warmup-ms (default 30 ms) have passed - the GPU's clocks "
+                                 "need ~3 ms of work to ramp up from idle, 40 bench steps of this workload; warmup_steps_run "
+                                 "is the count - (the first one carries a kernel timer, so the runtime's one-off set-up for "
+                                 "timed dispatches is not inside the timed region), barrier + synchronize, exactly K steps "
+                                 "+ the last rollout's deferred game-id scan (VecGame.join_ids), barrier + synchronize; gc.collect() + gc.freeze() before the warm-up; the kernel timer "
                                  "rides on every max(8, K/32)-th timed launch"},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -440,6 +440,16 @@ int ml2048_rollout_finish_ids(void *stream, int64_t M, const ml2048_state *st, i
                               const uint64_t *reset_flags, const int32_t *last_reset,
                               int32_t *game_count, int32_t *step_resets, int32_t *scratch);
 
+/* The id scan of a rollout issued later than its launch: ml2048_stream_wait_event(ids_stream, wait_event) (skipped when
+ * wait_event is NULL) + ml2048_rollout_finish_ids on ids_stream + done_event (may be NULL) recorded behind it, as one
+ * call.  VecGame.rollout(finish_ids="deferred") issues rollout k's scan on a side stream right AFTER the launch of
+ * rollout k+1 (so nothing is queued between two rollout kernels, and the scan runs beside kernel k+1), and the last
+ * rollout's scan on the launch stream itself when something finally needs the ids (VecGame.join_ids): no cross-stream
+ * wait sits between the last kernel and the end of a run. */
+int ml2048_rollout_ids_after(void *ids_stream, void *wait_event, int64_t M, const ml2048_state *st, int32_t N,
+                             const uint64_t *reset_flags, const int32_t *last_reset, int32_t *game_count,
+                             int32_t *step_resets, int32_t *scratch, void *done_event);
+
 /*
  * Front end of the reference's CNN encoder (CNNEncoder.forward, src/ml2048/policy/_network.py:84-119),
  * leaky_relu of the three depthwise convolutions over the one-hot board - whole board

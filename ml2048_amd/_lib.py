@@ -160,6 +160,8 @@ _SIGNATURES = {
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ml2048_rollout_finish_ids": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(State), C.c_int32, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ml2048_rollout_ids_after": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(State), C.c_int32, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

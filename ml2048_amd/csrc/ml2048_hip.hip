@@ -845,15 +845,16 @@ __global__ __launch_bounds__(EXTRAS ? kBlock : kRollMaxBlock) void k_rollout(ml2
             uint4 *l = reinterpret_cast<uint4 *>(lut_s);
             constexpr int kUnits = kRowLutEntries * 2 / 16, kInFlight = 8;
             const int nthr = (int)blockDim.x;
-            for (int k0 = (int)threadIdx.x; k0 < kUnits; k0 += kInFlight * nthr) {
-                uint4 v[kInFlight];
-#pragma unroll
-                for (int u = 0; u < kInFlight; ++u)
-                    if (k0 + u * nthr < kUnits) v[u] = g[k0 + u * nthr];
-#pragma unroll
-                for (int u = 0; u < kInFlight; ++u)
-                    if (k0 + u * nthr < kUnits) l[k0 + u * nthr] = v[u];
+            int k0 = (int)threadIdx.x;
+            // full rounds of eight unconditional requests per thread (a guarded form made the compiler stage the eight
+            // values through scratch memory: 32 MB of extra writes per launch at 262 144 boards), then the rest one by one
+            for (; k0 + (kInFlight - 1) * nthr < kUnits; k0 += kInFlight * nthr) {
+                const uint4 v0 = g[k0], v1 = g[k0 + nthr], v2 = g[k0 + 2 * nthr], v3 = g[k0 + 3 * nthr];
+                const uint4 v4 = g[k0 + 4 * nthr], v5 = g[k0 + 5 * nthr], v6 = g[k0 + 6 * nthr], v7 = g[k0 + 7 * nthr];
+                l[k0] = v0; l[k0 + nthr] = v1; l[k0 + 2 * nthr] = v2; l[k0 + 3 * nthr] = v3;
+                l[k0 + 4 * nthr] = v4; l[k0 + 5 * nthr] = v5; l[k0 + 6 * nthr] = v6; l[k0 + 7 * nthr] = v7;
             }
+            for (; k0 < kUnits; k0 += nthr) l[k0] = g[k0];
             __syncthreads();
         }
         // Chained upload: this launch also copies the NEXT rollout's packed schedule from device-accessible
@@ -2190,6 +2191,18 @@ int ml2048_rollout_chain_ids(void *stream, int64_t M, int64_t idx_base, const ml
         if (int rc = ml2048_stream_wait_event(ids_stream, rollout_event)) return rc;
     if (int rc = ml2048_rollout_finish_ids(ids_stream, M, st, N, reset_flags, last_reset, game_count, step_resets, scratch)) return rc;
     if (ids_done_event) return ml2048_event_record(ids_done_event, ids_stream);
+    return 0;
+}
+
+// ml2048_stream_wait_event(ids_stream, wait_event) + ml2048_rollout_finish_ids on ids_stream + done_event recorded behind
+// it, as ONE call: the id scan of the PREVIOUS rollout, issued by VecGame.rollout() right after the next rollout's launch
+int ml2048_rollout_ids_after(void *ids_stream, void *wait_event, int64_t M, const ml2048_state *st, int32_t N,
+                             const uint64_t *reset_flags, const int32_t *last_reset, int32_t *game_count,
+                             int32_t *step_resets, int32_t *scratch, void *done_event) {
+    if (wait_event)
+        if (int rc = ml2048_stream_wait_event(ids_stream, wait_event)) return rc;
+    if (int rc = ml2048_rollout_finish_ids(ids_stream, M, st, N, reset_flags, last_reset, game_count, step_resets, scratch)) return rc;
+    if (done_event) return ml2048_event_record(done_event, ids_stream);
     return 0;
 }
 

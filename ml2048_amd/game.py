@@ -206,6 +206,7 @@ class _RolloutBuffers(collections.abc.Mapping):
         return len(self._KEYS)
 
 
+_LAZY_IDS = os.environ.get("ML2048_LAZY_IDS", "1") != "0"  # see VecGame._rollout_plain_chain
 _ROW_LUTS: dict = {}  # device index -> the line table of the plain rollout kernels (constant data, 128 KiB)
 
 
@@ -275,6 +276,8 @@ class VecGame:
         self._ids_stream = None     # rollout(finish_ids="deferred"): side stream of the id scan ...
         self._ids_done = None       # ... its completion event, and whether the launch stream still has to
         self._ids_pending = False   # wait for it before anything touches ids / the game counter
+        self._lazy_scan = None      # the newest deferred plain rollout, whose id scan has not been issued yet
+        self._side_scans = False    # scans are in flight on the side stream (its _ids_done event is meaningful)
         self._spin = [None, None, None, None]  # pinned staging ring: [tensor, event of the launch that reads it]
         self._spin_i = 0
         self._roll_ev = None        # ring of per-rollout events (ONE per rollout: the kernel's own completion event)
@@ -370,13 +373,14 @@ class VecGame:
             main = self._raw_stream()
             roll_ev = self._next_roll_event()
             ids_stream, done, scratch = main, None, base + o_scratch
+            prev = None
             if finish_ids == "deferred":
                 # the rollout kernel reads neither ids nor the game counter, so the id scan of this rollout may run
-                # beside the NEXT rollout's kernel: a side stream, in order with the previous scans, joined by
-                # whatever touches ids next (join_ids)
-                side = self._ids_side_stream()
-                buf.record_stream(side)  # allocated on the launch stream, used on `side`
-                ids_stream, done = side.cuda_stream, self._ids_done.h
+                # beside the NEXT rollout's kernel.  It is not even issued now: the next rollout() call issues it on a
+                # side stream right behind ITS launch (nothing is ever queued between two rollout kernels), and whatever
+                # touches ids first issues it on the launch stream itself (join_ids) - no cross-stream wait between the
+                # last kernel of a run and its end (that wait, ~20 us, sat in every short run's tail).
+                prev, scratch = self._lazy_scan, None
             elif not finish_ids:
                 scratch = None
             if kernel_timer is not None:
@@ -388,18 +392,45 @@ class VecGame:
                 self._reward_kind, int(masked), int(act_seed), int(act_counter), base, base + o_last,
                 chain[0][0].data_ptr(), chain[1].data_ptr(), chain[2], chain[3], roll_ev.h, ids_stream,
                 self._game_count_dev.data_ptr(), base + o_resets, scratch, done), "rollout_chain_ids")
+            if finish_ids == "deferred":
+                if prev is not None:
+                    self._issue_scan(prev, on_side=True)
+                self._lazy_scan = (buf, N, base, base + o_last, base + o_resets, base + o_scratch, roll_ev)
+                if not _LAZY_IDS:  # A/B: this rollout's scan on the side stream at once (round 2's behaviour)
+                    rec, self._lazy_scan = self._lazy_scan, None
+                    self._issue_scan(rec, on_side=True)
+                self._ids_pending = True
         for ps in staged:  # the pinned slots this launch read: free once its marker has passed
             ps[1] = roll_ev
-        if finish_ids == "deferred":
-            self._ids_pending = True
         return _RolloutBuffers(buf, N, W, M, o_last, o_resets, bool(finish_ids))
+
+    def _issue_scan(self, rec, on_side: bool) -> None:
+        """Issue the ordered id scan of a deferred plain rollout (`rec`, see _rollout_plain_chain): on the side stream,
+        behind that rollout's event and the earlier scans - or on the launch stream (join_ids)."""
+        buf, N, p_flags, p_last, p_resets, p_scratch, roll_ev = rec
+        L = self._L
+        if on_side:
+            side = self._ids_side_stream()
+            buf.record_stream(side)  # allocated on the launch stream, used on `side`
+            stream, done = side.cuda_stream, self._ids_done.h
+            self._side_scans = True
+        else:
+            stream, done = self._raw_stream(), None
+        _lib.check(L.ml2048_rollout_ids_after(stream, roll_ev.h, self._size, self._st(), N, p_flags, p_last,
+                                              self._game_count_dev.data_ptr(), p_resets, p_scratch, done), "rollout_ids_after")
 
     def join_ids(self) -> None:
         """Order the launch stream after a deferred id scan (`rollout(finish_ids="deferred")`).  Every
         method of this class does it implicitly; call it before reading a deferred rollout's
         `step_resets` with your own torch code."""
         if self._ids_pending:
-            _lib.check(self._L.ml2048_stream_wait_event(self._raw_stream(), self._ids_done.h), "stream_wait_event")
+            with self._dev_ctx():
+                if self._side_scans:  # scans already issued on the side stream: the launch stream continues behind them
+                    _lib.check(self._L.ml2048_stream_wait_event(self._raw_stream(), self._ids_done.h), "stream_wait_event")
+                    self._side_scans = False
+                if self._lazy_scan is not None:  # the newest rollout's scan: on the launch stream itself
+                    rec, self._lazy_scan = self._lazy_scan, None
+                    self._issue_scan(rec, on_side=False)
             self._ids_pending = False
 
     @property
@@ -1278,6 +1309,10 @@ class VecGame:
                     # previous scans, joined by whatever touches ids next (join_ids)
                     main = torch.cuda.current_stream(dev)
                     side = self._ids_side_stream()
+                    if self._lazy_scan is not None:  # an older plain rollout's scan goes first (the game counter)
+                        rec, self._lazy_scan = self._lazy_scan, None
+                        self._issue_scan(rec, on_side=True)
+                    self._side_scans = True
                     _lib.check(L.ml2048_stream_wait_event(side.cuda_stream, roll_ev.h), "stream_wait_event")
                     for buf in (flags, last, step_resets, scratch):  # allocated on `main`, used on `side`
                         buf.record_stream(side)
