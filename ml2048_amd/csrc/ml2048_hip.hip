@@ -96,11 +96,7 @@ constexpr int kRollMaxBlock = 1024;
 constexpr int kRollMaxWaves = kRollMaxBlock / 64;
 // rollout steps whose re-deal flags are parked between flushes: in LDS (128 steps), or - ML2048_LONE_WAVE, the
 // small-M pass of the plain kernels - in a register pair, one step per lane (64 steps)
-#ifdef ML2048_LONE_WAVE
-constexpr int kFlagChunk = 64;
-#else
-constexpr int kFlagChunk = 128;
-#endif
+constexpr int kFlagChunk = 64; // (128 in LDS for the large-M pass until round 3: the LDS now holds the move's line table)
 #ifndef ML2048_STEP_UNROLL
 #define ML2048_STEP_UNROLL 8
 #endif
@@ -839,6 +835,26 @@ __global__ __launch_bounds__(EXTRAS ? kBlock : kRollMaxBlock) void k_rollout(ml2
     constexpr bool HAS_LUT = !EXTRAS;
 #endif
     __shared__ uint16_t lut_s[HAS_LUT ? kRowLutEntries : 8];
+    // The re-deal by LDS table too (large-M pass, table mode): a freshly dealt board is a function of the first two cells
+    // of its permutation row and of their two bits of the epoch's 2/4 mask - 1 024 boards of 16 bytes, filled by the
+    // workgroup itself; one ds_read_b128 and 8 VALU instead of the ~31 of deal_table_nibbles, in a block that runs
+    // whenever one of the wave's 64 games has ended (about every third step).  ML2048_DEAL_LDS=0: A/B.
+#if !defined(ML2048_DEAL_LDS) || ML2048_DEAL_LDS
+    constexpr bool DEAL_LDS = HAS_LUT && !FAST && INV;
+#else
+    constexpr bool DEAL_LDS = false;
+#endif
+    __shared__ uint4 deal_s[DEAL_LDS ? 1024 : 1];
+    if constexpr (DEAL_LDS) {
+        for (int e = (int)threadIdx.x; e < 1024; e += (int)blockDim.x) {
+            // index = c1 | c2 << 4 | (mask bit of cell c1) << 8 | (mask bit of cell c2) << 9
+            const uint32_t c1 = (uint32_t)e & 15u, c2 = ((uint32_t)e >> 4) & 15u;
+            const uint32_t m = ((((uint32_t)e >> 8) & 1u) << c1) | ((((uint32_t)e >> 9) & 1u) << c2);
+            Board d;
+            deal_table_nibbles(d, (uint32_t)e & 0xFFu, m);
+            deal_s[e] = make_uint4(d.r[0], d.r[1], d.r[2], d.r[3]);
+        }
+    }
     if constexpr (!EXTRAS) {
         if (HAS_LUT && row_lut) {
             const uint4 *g = reinterpret_cast<const uint4 *>(row_lut);
@@ -855,8 +871,8 @@ __global__ __launch_bounds__(EXTRAS ? kBlock : kRollMaxBlock) void k_rollout(ml2
                 l[k0 + 4 * nthr] = v4; l[k0 + 5 * nthr] = v5; l[k0 + 6 * nthr] = v6; l[k0 + 7 * nthr] = v7;
             }
             for (; k0 < kUnits; k0 += nthr) l[k0] = g[k0];
-            __syncthreads();
         }
+        if (DEAL_LDS || (HAS_LUT && row_lut)) __syncthreads();
         // Chained upload: this launch also copies the NEXT rollout's packed schedule from device-accessible
         // host memory into the other device buffer - ordered before the next launch by the stream itself,
         // so the upload needs neither a copy stream nor an event (a cross-stream wait in front of every
@@ -1139,7 +1155,11 @@ __global__ __launch_bounds__(EXTRAS ? kBlock : kRollMaxBlock) void k_rollout(ml2
                         spawn_word(s.board, w0, (uint32_t)thr);
                         spawn_word(s.board, w1, (uint32_t)thr);
                     } else {
-                        if (INV) {
+                        if (DEAL_LDS) {
+                            const uint32_t c1 = perm_p & 15u, c2 = ubfe(perm_p, 4, 4);
+                            const uint4 d = deal_s[(perm_p & 0xFFu) | (ubfe(two_mask, c1, 1) << 8) | (ubfe(two_mask, c2, 1) << 9)];
+                            s.board.r[0] = d.x; s.board.r[1] = d.y; s.board.r[2] = d.z; s.board.r[3] = d.w;
+                        } else if (INV) {
                             deal_table_nibbles(s.board, perm_p, two_mask);
                         } else {
                             const uint32_t head[4] = {perm_p, 0, 0, 0};
