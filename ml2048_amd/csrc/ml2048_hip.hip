@@ -835,12 +835,14 @@ __global__ __launch_bounds__(EXTRAS ? kBlock : kRollMaxBlock) void k_rollout(ml2
     constexpr bool HAS_LUT = !EXTRAS;
 #endif
     __shared__ uint16_t lut_s[HAS_LUT ? kRowLutEntries : 8];
-    // The re-deal by LDS table too (large-M pass, table mode): a freshly dealt board is a function of the first two cells
-    // of its permutation row and of their two bits of the epoch's 2/4 mask - 1 024 boards of 16 bytes, filled by the
+    // The re-deal by LDS table too (every plain pass, table mode): a freshly dealt board is a function of the first two
+    // cells of its permutation row and of their two bits of the epoch's 2/4 mask - 1 024 boards of 16 bytes, filled by the
     // workgroup itself; one ds_read_b128 and 8 VALU instead of the ~31 of deal_table_nibbles, in a block that runs
-    // whenever one of the wave's 64 games has ended (about every third step).  ML2048_DEAL_LDS=0: A/B.
+    // whenever one of the wave's 64 games has ended (about every third step).  262 144 boards: 2.09e11 -> 2.16e11
+    // board-steps/s end to end, masked 1.33e11 -> 1.39e11; 131 072 boards (small-M pass): 104.5 -> 101.7 us; C2 (one wave
+    // per SIMD: the look-up's round trip is exposed) 68.9 us either way.  ML2048_DEAL_LDS=0: A/B.
 #if !defined(ML2048_DEAL_LDS) || ML2048_DEAL_LDS
-    constexpr bool DEAL_LDS = HAS_LUT && !FAST && INV;
+    constexpr bool DEAL_LDS = !EXTRAS && !FAST && INV;
 #else
     constexpr bool DEAL_LDS = false;
 #endif
