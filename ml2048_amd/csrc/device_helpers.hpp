@@ -81,6 +81,32 @@ __device__ __forceinline__ void store_expanded_row(uint4 *dst, const uint32_t pe
     dst[2] = make_uint4(x[8], x[9], x[10], x[11]);
 }
 
+// spawn_table_dot (board_ops.hpp) with the tile looked up instead of shifted into place: `tiles` = 32 boards of 16 bytes in
+// LDS, entry c | bit << 4 = an empty board with the tile 2 - bit (a 2 where the epoch's mask bit of cell c is set, else a
+// 4) in cell c.  One ds_read_b128 instead of the value / 64-bit shift / half-of-the-board selects (~10 VALU), in the
+// passes whose other waves cover the look-up's round trip.
+template <bool HAS_EMPTY>
+__device__ __forceinline__ uint32_t spawn_table_dot_tiles(Board &b, uint32_t pn_lo, uint32_t pn_hi, const uint32_t wlo[4],
+                                                          const uint32_t whi[4], uint32_t two_mask, const uint4 *tiles) {
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t z = z_bytes(b.r[k]);
+        lo = udot4(z, wlo[k], lo);
+        hi = udot4(z, whi[k], hi);
+    }
+    const uint32_t hits = ((hi << 8) | lo) >> 7;
+    if (!HAS_EMPTY && hits == 0) return 0u; // a full board is left alone, as _spawn2 leaves it
+    const uint32_t i = (uint32_t)__builtin_ctz(hits);
+    const uint32_t c = ubfe((i & 8u) ? pn_hi : pn_lo, 4u * i, 4);
+    const uint4 t = tiles[c | (ubfe(two_mask, c, 1) << 4)];
+    b.r[0] |= t.x;
+    b.r[1] |= t.y;
+    b.r[2] |= t.z;
+    b.r[3] |= t.w;
+    return hits;
+}
+
 // One 16-byte unit of a schedule upload.  The source is a schedule-stream slot: [schedule | masks | epoch tables];
 // the units from `tab16` on are permutation rows: each goes out as a 48-byte expanded row, the header in front of
 // them is copied unchanged (tab16 >= the number of units: a plain copy).

@@ -847,6 +847,21 @@ __global__ __launch_bounds__(EXTRAS ? kBlock : kRollMaxBlock) void k_rollout(ml2
     constexpr bool DEAL_LDS = false;
 #endif
     __shared__ uint4 deal_s[DEAL_LDS ? 1024 : 1];
+    // ... and the spawned tile (device_helpers.hpp spawn_table_dot_tiles), where other waves share the SIMD (large-M pass)
+#if !defined(ML2048_TILE_LDS) || ML2048_TILE_LDS
+    constexpr bool TILE_LDS = HAS_LUT && !FAST && INV;
+#else
+    constexpr bool TILE_LDS = false;
+#endif
+    __shared__ uint4 tile_s[TILE_LDS ? 32 : 1];
+    if constexpr (TILE_LDS) {
+        if (threadIdx.x < 32) {
+            const uint32_t c = threadIdx.x & 15u, v = 2u - (threadIdx.x >> 4);
+            const uint32_t w = v << (8u * (c & 3u));
+            tile_s[threadIdx.x] = make_uint4((c >> 2) == 0u ? w : 0u, (c >> 2) == 1u ? w : 0u, (c >> 2) == 2u ? w : 0u,
+                                             (c >> 2) == 3u ? w : 0u);
+        }
+    }
     if constexpr (DEAL_LDS) {
         for (int e = (int)threadIdx.x; e < 1024; e += (int)blockDim.x) {
             // index = c1 | c2 << 4 | (mask bit of cell c1) << 8 | (mask bit of cell c2) << 9
@@ -874,7 +889,7 @@ __global__ __launch_bounds__(EXTRAS ? kBlock : kRollMaxBlock) void k_rollout(ml2
             }
             for (; k0 < kUnits; k0 += nthr) l[k0] = g[k0];
         }
-        if (DEAL_LDS || (HAS_LUT && row_lut)) __syncthreads();
+        if (DEAL_LDS || TILE_LDS || (HAS_LUT && row_lut)) __syncthreads();
         // Chained upload: this launch also copies the NEXT rollout's packed schedule from device-accessible
         // host memory into the other device buffer - ordered before the next launch by the stream itself,
         // so the upload needs neither a copy stream nor an event (a cross-stream wait in front of every
@@ -1214,7 +1229,8 @@ __global__ __launch_bounds__(EXTRAS ? kBlock : kRollMaxBlock) void k_rollout(ml2
                     if (FAST) {
                         empties = spawn_word(s.board, sw[0], (uint32_t)thr);
                     } else {
-                        if (INV) empties = spawn_table_dot<LAZY>(s.board, perm_s[0], perm_s[1], wlo_s, whi_s, two_mask);
+                        if (TILE_LDS) empties = spawn_table_dot_tiles<LAZY>(s.board, perm_s[0], perm_s[1], wlo_s, whi_s, two_mask, tile_s);
+                        else if (INV) empties = spawn_table_dot<LAZY>(s.board, perm_s[0], perm_s[1], wlo_s, whi_s, two_mask);
                         else spawn_table(s.board, perm_s, two_mask, 1);
                     }
                     if (LAZY && (FAST || INV)) step_post_lazy(s, empties);
