@@ -210,7 +210,7 @@ def rollout_roofline(M: int, N: int, avg_ms: float, masked: bool, traj: bool, sp
                 "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg,
                 "note": "algorithmic = the 54 B/board-step of REPLAY_SPEC transitions this launch writes"}
     variant = ("masked" if masked else "plain") + ("" if spawn == "table" else "-rocrand")
-    pass_ = "small" if M <= int(os.environ.get("ML2048_PLAIN_ILP_MAX", "131072")) else "large"  # launch_rollout's switch
+    pass_ = "small" if M <= int(os.environ.get("ML2048_PLAIN_ILP_MAX", "65536")) else "large"  # launch_rollout's switch
     ent = _inst_table().get(f"k_rollout:{variant}:{pass_}")
     tb, src = _traffic(f"k_rollout:M={M}:N={N}")
     r = {"bound": "valu_issue", "kernel": f"k_rollout<{variant}, {pass_}-M pass>", "unit": "G wave-instructions/s",

@@ -1936,9 +1936,10 @@ extern "C" {
 static int64_t plain_ilp_max_boards() {
     static const int64_t v = [] {
         const char *e = getenv("ML2048_PLAIN_ILP_MAX");
-        // up to two waves per SIMD: from three on the large-M pass with its LDS line table wins (196 608 boards: 138
-        // vs 151 us; 131 072: 110 vs 108 us, tools/debug/ilpmax_lut.sh)
-        return e ? (int64_t)atoll(e) : (int64_t)131072;
+        // one wave per SIMD: as soon as waves share a SIMD the large-M pass with its LDS tables (line table, re-deal,
+        // spawned tile) wins - 98 304 boards 96.6 vs 102.5 us, 131 072: 97.1 vs 103.3, 196 608: 138 vs 151 - while a
+        // lone wave pays every look-up's round trip (65 536: 78 vs 68 us; tools/debug/ilpmax_lut.sh, lut_ab.sh)
+        return e ? (int64_t)atoll(e) : (int64_t)65536;
     }();
     return v;
 }

@@ -98,8 +98,8 @@ def test_plain_c2_twice_back_to_back(amd, oracle):
 
 @pytest.mark.parametrize("M,lengths,reward,counter0", [
     (65536, [127, 65, 200], "improved", 13),   # remainder loop of the 8-step unroll; 64-step flag chunk edges
-    (131072, [128, 64], "rank", 0),            # largest M of the small-M passes (two waves per SIMD)
-    (131073, [128, 65], "maxcell", 77),        # smallest M of the large-M pass (LDS line table), ragged tail wave
+    (65537, [128, 64], "rank", 0),             # smallest M of the large-M pass (LDS tables): 5 board waves per workgroup
+    (131073, [128, 65], "maxcell", 77),        # 9 board waves per workgroup, ragged tail wave
     (196609, [65, 128], "improved", 40),       # 13 board waves per workgroup, the last workgroup partly past the boards
     (262144, [128, 128], "normal", 3),         # C4's per-GPU shard / C3's size
     (1000, [200, 65, 1], "improved", 31),      # ragged small M
