@@ -249,13 +249,19 @@ ML_HD uint16_t row_lut_entry(uint32_t idx) {
     return (uint16_t)((y & 0xFu) | ((y >> 4) & 0xF0u) | ((y >> 8) & 0xF00u) | ((y >> 12) & 0xF000u));
 }
 
-// move_board(in, action).board for boards whose lines are in the table's domain; lut[idx] = row_lut_entry(idx) for the
-// 65 536 line indices (in LDS on the device).
-// Measured and dropped (262 144 boards, tools/debug/sq_lut.sh): the low index byte XOR-ed with the high one so that the
-// small cell values of real play spread over the LDS banks (SQ_LDS_BANK_CONFLICT 47 -> 21 cycles per wave-step, kernel
-// 170 us either way: the look-up's round trip, not the LDS pipe, is what a wave waits for), and the next step's table
-// requests issued between the look-ups and their use (no change).
-template <class LutPtr>
+// Where a line's entry lives in the SWIZZLED form of the table.  LDS banks are picked by the low address bits, and in play
+// the cells are small numbers: with the plain index (cell 0 in bits 0-3, cell 1 in bits 4-7) most look-ups of a wave fall
+// on a dozen banks (12 of the 15 LDS cycles of a ds_read_u16 were bank conflicts).  XOR-ing the low byte with the high
+// byte shifted up by two - a bijection, one more VALU for the four lines of a board - brings the low bits of three cells
+// into the six bits that pick bank and half-word.  It pays where a wave is alone on its SIMD and waits out every
+// look-up (C2: 66.9 -> 65.1 us); with several waves per SIMD the extra instruction costs what the shorter LDS time gains
+// (262 144 boards: 147.8 vs 148.7 us), so the large-M pass keeps the plain index.
+ML_HD uint32_t row_lut_slot(uint32_t idx) { return idx ^ ((idx >> 6) & 0xFCu); }
+
+// move_board(in, action).board for boards whose lines are in the table's domain; lut[SWZ ? row_lut_slot(idx) : idx] =
+// row_lut_entry(idx) for the 65 536 line indices (in LDS on the device).
+// Measured and dropped: the next step's table requests issued between the look-ups and their use (C2: 67.0 vs 66.9 us).
+template <bool SWZ = false, class LutPtr>
 ML_HD Board move_board_lut(const Board &in, uint32_t action, LutPtr lut) {
     const bool horizontal = (action & 2u) == 0;
     const bool reverse = (action & 1u) != 0;
@@ -263,8 +269,9 @@ ML_HD Board move_board_lut(const Board &in, uint32_t action, LutPtr lut) {
     if (horizontal) b = transpose(b);
     const uint32_t a = reverse ? b.r[3] : b.r[0], bb = reverse ? b.r[2] : b.r[1];
     const uint32_t c = reverse ? b.r[1] : b.r[2], d = reverse ? b.r[0] : b.r[3];
-    // byte j of n01 / n23 = the low / high byte of line j's index
-    const uint32_t n01 = a | (bb << 4), n23 = c | (d << 4);
+    // byte j of n01 / n23 = the low / high byte of line j's index (row_lut_slot on all four lines at once)
+    const uint32_t n23 = c | (d << 4);
+    const uint32_t n01 = SWZ ? (a | (bb << 4)) ^ ((n23 << 2) & 0xFCFCFCFCu) : a | (bb << 4);
     const uint32_t r0 = lut[perm_b32(n23, n01, 0x0c0c0400u)];
     const uint32_t r1 = lut[perm_b32(n23, n01, 0x0c0c0501u)];
     const uint32_t r2 = lut[perm_b32(n23, n01, 0x0c0c0602u)];
@@ -850,10 +857,10 @@ ML_HD bool step_pre_lazy_pv(StepRegs &s, uint32_t action, Board &pv, uint32_t &p
 }
 
 // the two steps above with the move looked up (move_board_lut; callers establish lut_guard first)
-template <class LutPtr>
+template <bool SWZ = false, class LutPtr>
 ML_HD bool step_pre_lazy_pv_lut(StepRegs &s, uint32_t action, Board &pv, uint32_t &pv_action, LutPtr lut) {
     const Board prev = s.board;
-    const Board nb = move_board_lut(prev, action & 3u, lut);
+    const Board nb = move_board_lut<SWZ>(prev, action & 3u, lut);
     if (action >= 4u || !board_differs(nb, prev)) return false;
     pv = prev;
     pv_action = action;
@@ -861,13 +868,13 @@ ML_HD bool step_pre_lazy_pv_lut(StepRegs &s, uint32_t action, Board &pv, uint32_
     s.step += 1;
     return true;
 }
-template <class LutPtr>
+template <bool SWZ = false, class LutPtr>
 ML_HD bool step_pre_lite_pv_lut(StepRegs &s, uint32_t action, Board &pv, uint32_t &pv_action, LutPtr lut) {
     const bool ok = action < 4u && ((s.valid >> (8u * (action & 3u))) & 0xFFu) != 0u;
     if (!ok) return false;
     pv = s.board;
     pv_action = action;
-    s.board = move_board_lut(pv, action, lut);
+    s.board = move_board_lut<SWZ>(pv, action, lut);
     s.step += 1;
     return true;
 }

@@ -824,15 +824,17 @@ __global__ __launch_bounds__(EXTRAS ? kBlock : kRollMaxBlock) void k_rollout(ml2
     __shared__ unsigned long long flag_park[EXTRAS ? kBlock / 64 : kRollMaxWaves][kFlagChunk];
 #endif
     // The line table (board_ops.hpp move_board_lut): 65 536 x uint16 in LDS, copied from the caller's device buffer by
-    // the whole workgroup (16-byte units, eight requests in flight per thread).  Only in the large-M pass: with several
-    // waves per SIMD the ~85 VALU of the arithmetic move are what bounds the kernel and the LDS round trip of a look-up
-    // hides behind the other waves (262 144 boards: 189 -> 170 us); a lone wave per SIMD pays that round trip in full
-    // every step (C2: 68 -> 78 us, SQ_WAIT_ANY 63 -> 147 quad-cycles per wave-step), so the small-M passes keep the
-    // arithmetic move and no table (tools/debug/lut_ab.sh, sq_lut.sh).
-#ifdef ML2048_LONE_WAVE
-    constexpr bool HAS_LUT = false;
-#else
+    // the whole workgroup (16-byte units, eight requests in flight per thread: ~2 us).  With several waves per SIMD the
+    // ~85 VALU of the arithmetic move are what bounds the kernel and a look-up's round trip hides behind the other waves
+    // (262 144 boards: 189 -> 158 us); a wave alone on its SIMD waits the ~65 cycles out every step and still gains
+    // (C2: 68.9 -> 66.9 us, 65.1 with the table's entries spread over the LDS banks: LUT_SWZ, board_ops.hpp row_lut_slot -
+    // the small-M passes store the table swizzled, the large-M pass plain).  (Round 3's first measurement of the
+    // small-M form read 78 us: its loader staged the table through scratch memory.)
     constexpr bool HAS_LUT = !EXTRAS;
+#ifdef ML2048_LONE_WAVE
+    constexpr bool LUT_SWZ = true;
+#else
+    constexpr bool LUT_SWZ = false;
 #endif
     __shared__ uint16_t lut_s[HAS_LUT ? kRowLutEntries : 8];
     // The re-deal by LDS table too (every plain pass, table mode): a freshly dealt board is a function of the first two
@@ -849,7 +851,7 @@ __global__ __launch_bounds__(EXTRAS ? kBlock : kRollMaxBlock) void k_rollout(ml2
     __shared__ uint4 deal_s[DEAL_LDS ? 1024 : 1];
     // ... and the spawned tile (device_helpers.hpp spawn_table_dot_tiles), where other waves share the SIMD (large-M pass)
 #if !defined(ML2048_TILE_LDS) || ML2048_TILE_LDS
-    constexpr bool TILE_LDS = HAS_LUT && !FAST && INV;
+    constexpr bool TILE_LDS = HAS_LUT && !FAST && INV && !LUT_SWZ; // (a lone wave loses: C2 68.3 vs 66.9 us)
 #else
     constexpr bool TILE_LDS = false;
 #endif
@@ -881,13 +883,22 @@ __global__ __launch_bounds__(EXTRAS ? kBlock : kRollMaxBlock) void k_rollout(ml2
             int k0 = (int)threadIdx.x;
             // full rounds of eight unconditional requests per thread (a guarded form made the compiler stage the eight
             // values through scratch memory: 32 MB of extra writes per launch at 262 144 boards), then the rest one by one
+            // (LUT_SWZ: unit u = entries 8u .. 8u+7 of the plain table; row_lut_slot moves it to unit u ^ ((u >> 6) & 31)
+            // and swaps its halves when bit 5 of u is set - the slot function XORs bits 2..7 of an index with bits 8..13)
+            auto put = [&](int u, uint4 v) __attribute__((always_inline)) {
+                if (LUT_SWZ) {
+                    if (u & 32) v = make_uint4(v.z, v.w, v.x, v.y);
+                    u ^= (u >> 6) & 31;
+                }
+                l[u] = v;
+            };
             for (; k0 + (kInFlight - 1) * nthr < kUnits; k0 += kInFlight * nthr) {
                 const uint4 v0 = g[k0], v1 = g[k0 + nthr], v2 = g[k0 + 2 * nthr], v3 = g[k0 + 3 * nthr];
                 const uint4 v4 = g[k0 + 4 * nthr], v5 = g[k0 + 5 * nthr], v6 = g[k0 + 6 * nthr], v7 = g[k0 + 7 * nthr];
-                l[k0] = v0; l[k0 + nthr] = v1; l[k0 + 2 * nthr] = v2; l[k0 + 3 * nthr] = v3;
-                l[k0 + 4 * nthr] = v4; l[k0 + 5 * nthr] = v5; l[k0 + 6 * nthr] = v6; l[k0 + 7 * nthr] = v7;
+                put(k0, v0); put(k0 + nthr, v1); put(k0 + 2 * nthr, v2); put(k0 + 3 * nthr, v3);
+                put(k0 + 4 * nthr, v4); put(k0 + 5 * nthr, v5); put(k0 + 6 * nthr, v6); put(k0 + 7 * nthr, v7);
             }
-            for (; k0 < kUnits; k0 += nthr) l[k0] = g[k0];
+            for (; k0 < kUnits; k0 += nthr) put(k0, g[k0]);
         }
         if (DEAL_LDS || TILE_LDS || (HAS_LUT && row_lut)) __syncthreads();
         // Chained upload: this launch also copies the NEXT rollout's packed schedule from device-accessible
@@ -1221,8 +1232,8 @@ __global__ __launch_bounds__(EXTRAS ? kBlock : kRollMaxBlock) void k_rollout(ml2
                 // ---- step (game_numba.py:660-738)
                 prev_board = s.board;
                 if (!LAZY) prev_valid = s.valid;
-                if (LAZY    ? (LUT ? step_pre_lazy_pv_lut(s, action, pv, pv_action, lut_s) : step_pre_lazy_pv(s, action, pv, pv_action))
-                    : DEFER ? (LUT ? step_pre_lite_pv_lut(s, action, pv, pv_action, lut_s) : step_pre_lite_pv(s, action, pv, pv_action))
+                if (LAZY    ? (LUT ? step_pre_lazy_pv_lut<LUT_SWZ>(s, action, pv, pv_action, lut_s) : step_pre_lazy_pv(s, action, pv, pv_action))
+                    : DEFER ? (LUT ? step_pre_lite_pv_lut<LUT_SWZ>(s, action, pv, pv_action, lut_s) : step_pre_lite_pv(s, action, pv, pv_action))
                             : step_pre_lite(s, action, KIND, mexp_first, mexp_second)) {
                     merged_stale = true;
                     uint32_t empties = 0;

@@ -90,10 +90,10 @@ int64_t h_move_forms_check(const uint8_t *boards, int64_t n) {
 // inside the table's domain (exponents <= 15, no merge of two 2^15 tiles); boards outside it are skipped and counted
 // in *skipped.  Also checks lut_guard: a board it accepts must be in the domain for every direction.
 int64_t h_move_lut_check(const uint8_t *boards, int64_t n, int64_t *skipped) {
-    static uint16_t lut[kRowLutEntries];
+    static uint16_t lut[kRowLutEntries], lut_swz[kRowLutEntries]; // plain and bank-swizzled layout (row_lut_slot)
     static bool filled = false;
     if (!filled) {
-        for (uint32_t i = 0; i < (uint32_t)kRowLutEntries; ++i) lut[i] = row_lut_entry(i);
+        for (uint32_t i = 0; i < (uint32_t)kRowLutEntries; ++i) lut[i] = lut_swz[row_lut_slot(i)] = row_lut_entry(i);
         filled = true;
     }
     int64_t bad = 0, skip = 0;
@@ -110,8 +110,8 @@ int64_t h_move_lut_check(const uint8_t *boards, int64_t n, int64_t *skipped) {
                 ++skip;
                 continue;
             }
-            const Board y = move_board_lut(b, a, lut);
-            if (memcmp(x.board.r, y.r, 16) != 0) ++bad;
+            const Board y = move_board_lut<false>(b, a, lut), z = move_board_lut<true>(b, a, lut_swz);
+            if (memcmp(x.board.r, y.r, 16) != 0 || memcmp(x.board.r, z.r, 16) != 0) ++bad;
         }
     }
     *skipped = skip;
