@@ -640,6 +640,18 @@ ML_HD uint32_t spawn_word(Board &b, uint32_t w, uint32_t thr16) {
     return empties;
 }
 
+// The two spawns of a re-deal in the counter-based mode (spawn_word twice on an empty board) as an index into the table
+// of dealt boards that the fused rollout keeps in LDS (deal_table_nibbles' index: c1 | c2 << 4 | "tile 1 is a 2" << 8 |
+// "tile 2 is a 2" << 9).  On an empty board the first word's cell is its top four bits (k = (hi16 * 16) >> 16), the
+// second picks the k-th of the remaining fifteen cells.  ~15 VALU instead of two k-th-empty-cell selections (~120).
+ML_HD uint32_t deal_words_index(uint32_t w0, uint32_t w1, uint32_t thr16) {
+    const uint32_t c1 = w0 >> 28;
+    const uint32_t k2 = ((w1 >> 16) * 15u) >> 16;
+    const uint32_t c2 = k2 + (k2 >= c1 ? 1u : 0u);
+    const uint32_t b1 = (w0 & 0xFFFFu) < thr16 ? 0x100u : 0u, b2 = (w1 & 0xFFFFu) < thr16 ? 0x200u : 0u;
+    return c1 | (c2 << 4) | b1 | b2;
+}
+
 ML_HD uint32_t max_cell(const Board &b) {
     uint32_t mx = 0;
 #pragma unroll

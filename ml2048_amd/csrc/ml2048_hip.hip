@@ -844,7 +844,7 @@ __global__ __launch_bounds__(EXTRAS ? kBlock : kRollMaxBlock) void k_rollout(ml2
     // board-steps/s end to end, masked 1.33e11 -> 1.39e11; 131 072 boards (small-M pass): 104.5 -> 101.7 us; C2 (one wave
     // per SIMD: the look-up's round trip is exposed) 68.9 us either way.  ML2048_DEAL_LDS=0: A/B.
 #if !defined(ML2048_DEAL_LDS) || ML2048_DEAL_LDS
-    constexpr bool DEAL_LDS = !EXTRAS && !FAST && INV;
+    constexpr bool DEAL_LDS = !EXTRAS && (FAST || INV); // (rocRAND mode: board_ops.hpp deal_words_index)
 #else
     constexpr bool DEAL_LDS = false;
 #endif
@@ -1180,8 +1180,13 @@ __global__ __launch_bounds__(EXTRAS ? kBlock : kRollMaxBlock) void k_rollout(ml2
                     if (FAST) {
                         uint32_t w0, w1;
                         rocrand_deal_words(spawn_seed, spawn_counter0 + (uint64_t)t, (uint64_t)(idx_base + ii), w0, w1);
-                        spawn_word(s.board, w0, (uint32_t)thr);
-                        spawn_word(s.board, w1, (uint32_t)thr);
+                        if (DEAL_LDS) {
+                            const uint4 d = deal_s[deal_words_index(w0, w1, (uint32_t)thr)];
+                            s.board.r[0] = d.x; s.board.r[1] = d.y; s.board.r[2] = d.z; s.board.r[3] = d.w;
+                        } else {
+                            spawn_word(s.board, w0, (uint32_t)thr);
+                            spawn_word(s.board, w1, (uint32_t)thr);
+                        }
                     } else {
                         if (DEAL_LDS) {
                             const uint32_t c1 = perm_p & 15u, c2 = ubfe(perm_p, 4, 4);

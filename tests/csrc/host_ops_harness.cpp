@@ -118,6 +118,26 @@ int64_t h_move_lut_check(const uint8_t *boards, int64_t n, int64_t *skipped) {
     return bad;
 }
 
+// the counter-based re-deal as a table index (deal_words_index + deal_table_nibbles' table) == spawn_word twice on an
+// empty board, on n word pairs; returns the number of differences
+int64_t h_deal_words_check(const uint32_t *words, int64_t n, uint32_t thr16) {
+    int64_t bad = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t w0 = words[2 * i], w1 = words[2 * i + 1];
+        Board a;
+        a.r[0] = a.r[1] = a.r[2] = a.r[3] = 0;
+        spawn_word(a, w0, thr16);
+        spawn_word(a, w1, thr16);
+        const uint32_t idx = deal_words_index(w0, w1, thr16);
+        const uint32_t c1 = idx & 15u, c2 = (idx >> 4) & 15u;
+        const uint32_t m = (((idx >> 8) & 1u) << c1) | (((idx >> 9) & 1u) << c2);
+        Board b;
+        deal_table_nibbles(b, idx & 0xFFu, m); // what the kernel's LDS table holds at `idx`
+        if (c1 == c2 || idx >= 1024u || memcmp(a.r, b.r, 16) != 0) ++bad;
+    }
+    return bad;
+}
+
 // stable compaction by position masks (compact_cells) == the six-step bubble it replaced, on n x 4 cell words
 int64_t h_compact_check(const uint32_t *words, int64_t n) {
     int64_t bad = 0;

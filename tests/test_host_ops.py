@@ -38,6 +38,8 @@ def H():
     L.h_move_forms_check.restype = i64
     L.h_move_lut_check.argtypes = [vp, i64, vp]
     L.h_move_lut_check.restype = i64
+    L.h_deal_words_check.argtypes = [vp, i64, C.c_uint32]
+    L.h_deal_words_check.restype = i64
     L.h_lazy_mask_check.argtypes = [vp, i64]
     L.h_lazy_mask_check.restype = i64
     L.h_step.argtypes = [vp, i64, i64, vp, vp, vp, i32, dbl, i64, vp, vp]
@@ -245,6 +247,18 @@ def test_move_by_table_lookup_equals_the_arithmetic_move(H):
     skipped = np.zeros(1, np.int64)
     assert H.h_move_lut_check(_p(allb), allb.shape[0], _p(skipped)) == 0
     assert 0 < skipped[0] < allb.shape[0]          # the 2^15 + 2^15 lines and the boards above 2^15 were there
+
+
+def test_counter_based_redeal_as_a_table_index(H):
+    """deal_words_index (rocRAND spawn mode's re-deal as an index into the LDS table of dealt boards) == spawn_word twice
+    on an empty board, for random word pairs, the edge words, and thresholds 0, 0.8, 1."""
+    rng = np.random.default_rng(8)
+    words = rng.integers(0, 2**32, size=(400000, 2), dtype=np.uint64).astype(np.uint32)
+    edges = np.array([[0, 0], [0xFFFFFFFF, 0xFFFFFFFF], [0xF0000000, 0xEFFF0000], [0x10000000, 0x11110000], [0, 0xFFFF0000],
+                      [0xFFFF0000, 0], [0x7FFFCCCC, 0x8000CCCD]], np.uint32)
+    allw = np.ascontiguousarray(np.concatenate([edges, words]))
+    for thr in (0, 52429, 65536, 1, 65535):
+        assert H.h_deal_words_check(_p(allw), allw.shape[0], thr) == 0
 
 
 def test_compaction_by_position_masks_equals_the_bubble(H):
