@@ -84,6 +84,14 @@ def test_argument_validation_without_gpu(lib):
     assert lib.ml2048_rollout_chain_ids(None, 64, 0, C.byref(ok), 8, 4096, 4096, 1, 4096, 0, 0, 0, 0, 4096, 4096, None, None,
                                         0, 0, None, 8192, 4096, 4096, 4096, None) == -1   # side-stream scan without a marker
     assert b"rollout_event" in lib.ml2048_last_error()
+    # round 3: the line table and the late id scan reject bad arguments before any launch too
+    assert lib.ml2048_row_lut_fill(None, None) == -2 and lib.ml2048_row_lut_fill(None, 4100) == -2
+    assert b"16-byte aligned" in lib.ml2048_last_error()
+    assert lib.ml2048_rollout_attach_row_lut(4104) == 0                  # (one-shot: consumed - and refused - by the next launch)
+    assert lib.ml2048_rollout_chain(None, 64, 0, C.byref(ok), 8, 4096, 4096, 1, 4096, 0, 0, 0, 0, 4096, 4096,
+                                    None, None, 0, 0) == -2 and b"row_lut" in lib.ml2048_last_error()
+    assert lib.ml2048_rollout_ids_after(None, None, 64, C.byref(ok), 8, None, None, None, None, None, None) == -1
+    assert lib.ml2048_rollout_ids_after(None, None, -1, C.byref(ok), 8, 4096, 4096, 4096, 4096, 4096, None) == -1
     assert lib.ml2048_sched_stream_slot_bytes(0) == 0
     assert lib.ml2048_sched_stream_slot_bytes(128) == 1536 + 528 + 129 * 1024 * 16
     assert not lib.ml2048_sched_stream_create_pinned(None, None, None, 0, 128, 0.8, 4, None, 0)
