@@ -92,8 +92,14 @@ int check_launch(const char *what) {
 constexpr int kBlock = 256;      // threads per workgroup for the per-board kernels (4 waves)
 // The plain rollout kernels hold the 128 KiB line table in LDS, i.e. ONE workgroup per compute unit: the workgroup is
 // sized at launch to the CU's whole share of the boards, up to 16 waves (4 per SIMD).
+#ifdef ML2048_LONE_WAVE
+// the small-M passes serve at most 8 board waves per workgroup (+ the upload wave; launch_rollout): the smaller bound lets
+// the compiler use 168 VGPRs instead of 128 (the rank / maxcell reward kinds spilled 8-14 VGPRs under the 1 024 bound)
+constexpr int kRollMaxBlock = 576;
+#else
 constexpr int kRollMaxBlock = 1024;
-constexpr int kRollMaxWaves = kRollMaxBlock / 64;
+#endif
+constexpr int kRollMaxWaves = 16;
 // rollout steps whose re-deal flags are parked between flushes: in LDS (128 steps), or - ML2048_LONE_WAVE, the
 // small-M pass of the plain kernels - in a register pair, one step per lane (64 steps)
 constexpr int kFlagChunk = 64; // (128 in LDS for the large-M pass until round 3: the LDS now holds the move's line table)
@@ -892,6 +898,8 @@ __global__ __launch_bounds__(EXTRAS ? kBlock : kRollMaxBlock) void k_rollout(ml2
                 }
                 l[u] = v;
             };
+            // (sixteen requests in flight for the small workgroups - two L2 round trips instead of three full rounds and
+            // two single requests - measured slower: C2 66.3 vs 65.5 us)
             for (; k0 + (kInFlight - 1) * nthr < kUnits; k0 += kInFlight * nthr) {
                 const uint4 v0 = g[k0], v1 = g[k0 + nthr], v2 = g[k0 + 2 * nthr], v3 = g[k0 + 3 * nthr];
                 const uint4 v4 = g[k0 + 4 * nthr], v5 = g[k0 + 5 * nthr], v6 = g[k0 + 6 * nthr], v7 = g[k0 + 7 * nthr];
@@ -2033,7 +2041,7 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
         a.reset_flags = reset_flags, a.flag_words = W, a.last_reset = last_reset;
         a.spawn_seed = spawn_seed, a.spawn_counter0 = spawn_counter0, a.two_threshold = thr;
         a.up_src = (const uint4 *)up_src, a.up_dst = (uint4 *)up_dst, a.up_n16 = up_n16, a.up_blocks = up_mode, a.up_tab16 = up_tab16;
-        const bool small = M <= plain_ilp_max_boards();
+        const bool small = M <= plain_ilp_max_boards() && bw <= 8; // (the small-M passes' launch bound: 8 + 1 waves)
         if (small ? (!fast && !masked ? ml2048_internal_launch_rollout_plain_lone(reward_kind, fast, inv_tables, a)
                                       : ml2048_internal_launch_rollout_plain_ilp(reward_kind, fast, inv_tables, a))
                   : ml2048_internal_launch_rollout_plain_dflt(reward_kind, fast, inv_tables, a))
