@@ -2034,7 +2034,7 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
         ml2048_plain_launch a;
         a.grid = dim3((unsigned)cdiv(waves, bw)), a.block = dim3(64u * (unsigned)(bw + (up_mode == 1u ? 1 : 0)));
         a.stream = s, a.ev_start = ev_start, a.ev_stop = ev_stop;
-        a.row_lut = row_lut, a.board_waves = bw;
+        a.board_waves = bw;
         a.st = *st, a.M = M, a.idx_base = idx_base, a.N = N;
         a.perm_epochs = perm_epochs, a.two_masks = two_masks, a.schedule = schedule, a.n_epochs = n_epochs;
         a.masked = masked, a.act_seed = act_seed, a.act_counter0 = act_counter0;
@@ -2042,6 +2042,9 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
         a.spawn_seed = spawn_seed, a.spawn_counter0 = spawn_counter0, a.two_threshold = thr;
         a.up_src = (const uint4 *)up_src, a.up_dst = (uint4 *)up_dst, a.up_n16 = up_n16, a.up_blocks = up_mode, a.up_tab16 = up_tab16;
         const bool small = M <= plain_ilp_max_boards() && bw <= 8; // (the small-M passes' launch bound: 8 + 1 waves)
+        // copying the line table into LDS costs ~2.5 us per launch; a step gains ~0.05 us from it in the small-M passes
+        // and ~0.3 us in the large-M pass: short rollouts move arithmetically
+        a.row_lut = N >= (small ? 64 : 16) ? row_lut : nullptr;
         if (small ? (!fast && !masked ? ml2048_internal_launch_rollout_plain_lone(reward_kind, fast, inv_tables, a)
                                       : ml2048_internal_launch_rollout_plain_ilp(reward_kind, fast, inv_tables, a))
                   : ml2048_internal_launch_rollout_plain_dflt(reward_kind, fast, inv_tables, a))
