@@ -426,6 +426,14 @@ int ml2048_rollout_traj(void *stream, int64_t M, int64_t idx_base, const ml2048_
                         uint64_t act_counter0, uint64_t *reset_flags, int32_t *last_reset,
                         const ml2048_traj *traj);
 
+/* ml2048_rollout_traj on EXPANDED tables (perm_epochs as ml2048_rollout_chain reads it: ML2048_EXPANDED_ROW_BYTES per row,
+ * produced by ml2048_upload with table_offset < nbytes - from host or device memory): the dot-product spawn instead of
+ * sixteen probes, the re-deal and the spawned tile as LDS look-ups; same results. */
+int ml2048_rollout_traj_expanded(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
+                                 const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,
+                                 const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0,
+                                 uint64_t *reset_flags, int32_t *last_reset, const ml2048_traj *traj);
+
 /* The same fused rollout in rocRAND spawn mode: no host schedule at all.  Equals N calls of
  * ml2048_prepare_fast(counter = spawn_counter0+t) / ml2048_sample_actions / ml2048_step_fast(
  * counter = spawn_counter0+t); bit-exact against the oracle's orc_*_fast, not against numba. */

@@ -155,6 +155,9 @@ _SIGNATURES = {
     "ml2048_rollout_traj": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_int32, C.c_void_p,
                                       C.c_void_p, C.c_int32, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                       C.c_void_p, C.c_void_p, C.POINTER(Traj)]),
+    "ml2048_rollout_traj_expanded": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_int32, C.c_void_p,
+                                               C.c_void_p, C.c_int32, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
+                                               C.c_void_p, C.c_void_p, C.POINTER(Traj)]),
     "ml2048_rollout_fast": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(State), C.c_int32, C.c_double,
                                       C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

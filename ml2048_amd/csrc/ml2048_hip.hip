@@ -850,14 +850,15 @@ __global__ __launch_bounds__(EXTRAS ? kBlock : kRollMaxBlock) void k_rollout(ml2
     // board-steps/s end to end, masked 1.33e11 -> 1.39e11; 131 072 boards (small-M pass): 104.5 -> 101.7 us; C2 (one wave
     // per SIMD: the look-up's round trip is exposed) 68.9 us either way.  ML2048_DEAL_LDS=0: A/B.
 #if !defined(ML2048_DEAL_LDS) || ML2048_DEAL_LDS
-    constexpr bool DEAL_LDS = !EXTRAS && (FAST || INV); // (rocRAND mode: board_ops.hpp deal_words_index)
+    constexpr bool DEAL_LDS = EXTRAS ? INV : (FAST || INV); // (rocRAND mode: board_ops.hpp deal_words_index)
 #else
     constexpr bool DEAL_LDS = false;
 #endif
     __shared__ uint4 deal_s[DEAL_LDS ? 1024 : 1];
     // ... and the spawned tile (device_helpers.hpp spawn_table_dot_tiles), where other waves share the SIMD (large-M pass)
 #if !defined(ML2048_TILE_LDS) || ML2048_TILE_LDS
-    constexpr bool TILE_LDS = HAS_LUT && !FAST && INV && !LUT_SWZ; // (a lone wave loses: C2 68.3 vs 66.9 us)
+    // (a lone wave loses: C2 68.3 vs 66.9 us; the trajectory-writing instantiations on expanded tables take it too)
+    constexpr bool TILE_LDS = !FAST && INV && !LUT_SWZ;
 #else
     constexpr bool TILE_LDS = false;
 #endif
@@ -908,7 +909,9 @@ __global__ __launch_bounds__(EXTRAS ? kBlock : kRollMaxBlock) void k_rollout(ml2
             }
             for (; k0 < kUnits; k0 += nthr) put(k0, g[k0]);
         }
-        if (DEAL_LDS || TILE_LDS || (HAS_LUT && row_lut)) __syncthreads();
+    }
+    if (DEAL_LDS || TILE_LDS || (HAS_LUT && row_lut)) __syncthreads();
+    if constexpr (!EXTRAS) {
         // Chained upload: this launch also copies the NEXT rollout's packed schedule from device-accessible
         // host memory into the other device buffer - ordered before the next launch by the stream itself,
         // so the upload needs neither a copy stream nor an event (a cross-stream wait in front of every
@@ -2023,7 +2026,7 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
         g_stop_event_attached = true;
     }
     g_attach_stop_event = nullptr;
-    if (inv_tables && (fast || extras)) return fail(ML2048_E_UNSUPPORTED, "expanded tables: plain table-mode rollouts only");
+    if (inv_tables && fast) return fail(ML2048_E_UNSUPPORTED, "expanded tables: table-mode rollouts only");
     if (extras && up_n16 > 0) return fail(ML2048_E_UNSUPPORTED, "chained upload: plain rollouts only");
     if (!extras) { // the plain instantiations live in their own compilation passes (see ml2048_plain_launch)
         // one workgroup = one compute unit's share of the boards (the LDS line table leaves room for one workgroup per
@@ -2051,8 +2054,9 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
             return fail(ML2048_E_INVALID, "reward_kind=%d", reward_kind);
         return check_launch("ml2048_rollout");
     }
-#define ML_LAUNCH2(K, F)                                                                                     \
-    hipExtLaunchKernelGGL((k_rollout<K, F, true, false>), grid, block, 0, s, ev_start, ev_stop, 0, *st, M, idx_base, N, perm_epochs, two_masks, \
+#define ML_LAUNCH2(K, F) ML_LAUNCH3(K, F, false)
+#define ML_LAUNCH3(K, F, I)                                                                                  \
+    hipExtLaunchKernelGGL((k_rollout<K, F, true, I>), grid, block, 0, s, ev_start, ev_stop, 0, *st, M, idx_base, N, perm_epochs, two_masks, \
                        schedule, n_epochs, masked, act_seed, act_counter0, actions_out, digests_out,         \
                        reset_flags, W,                                                                       \
                        last_reset, spawn_seed, spawn_counter0, thr, traj, (const uint4 *)nullptr, (uint4 *)nullptr, (int64_t)0, 0u, (int64_t)0, \
@@ -2067,10 +2071,19 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
     }
     if (fast) {
         ML_KIND(true)
+    } else if (inv_tables) { // optional outputs on expanded tables: dot-product spawn, re-deal and spawned tile by LDS look-ups
+        switch (reward_kind) {
+        case ML2048_REWARD_NORMAL: ML_LAUNCH3(REWARD_NORMAL, false, true); break;
+        case ML2048_REWARD_IMPROVED: ML_LAUNCH3(REWARD_IMPROVED, false, true); break;
+        case ML2048_REWARD_RANK: ML_LAUNCH3(REWARD_RANK, false, true); break;
+        case ML2048_REWARD_MAXCELL: ML_LAUNCH3(REWARD_MAXCELL, false, true); break;
+        default: return fail(ML2048_E_INVALID, "reward_kind=%d", reward_kind);
+        }
     } else {
         ML_KIND(false)
     }
 #undef ML_KIND
+#undef ML_LAUNCH3
 #undef ML_LAUNCH2
     return check_launch("ml2048_rollout");
 }
@@ -2118,6 +2131,21 @@ int ml2048_rollout_traj(void *stream, int64_t M, int64_t idx_base, const ml2048_
     if (idx_base < 0) return fail(ML2048_E_INVALID, "idx_base must be >= 0");
     return launch_rollout((hipStream_t)stream, false, M, idx_base, st, N, perm_epochs, two_masks, schedule, n_epochs, reward_kind,
                           masked, act_seed, act_counter0, nullptr, nullptr, reset_flags, last_reset, 0, 0, 0.0, traj);
+}
+
+int ml2048_rollout_traj_expanded(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,
+                                 const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,
+                                 const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0,
+                                 uint64_t *reset_flags, int32_t *last_reset, const ml2048_traj *traj) {
+    if (int rc = check_state(M, st)) return rc;
+    if (N <= 0 || n_epochs <= 0) return fail(ML2048_E_INVALID, "N=%d n_epochs=%d must be positive", N, n_epochs);
+    if (!perm_epochs || !two_masks || !schedule || !reset_flags || !last_reset || !traj)
+        return fail(ML2048_E_INVALID, "perm_epochs/two_masks/schedule/reset_flags/last_reset/traj is NULL");
+    if ((uintptr_t)perm_epochs % 16) return fail(ML2048_E_ALIGN, "perm_epochs must be 16-byte aligned");
+    if (idx_base < 0) return fail(ML2048_E_INVALID, "idx_base must be >= 0");
+    return launch_rollout((hipStream_t)stream, false, M, idx_base, st, N, perm_epochs, two_masks, schedule, n_epochs, reward_kind,
+                          masked, act_seed, act_counter0, nullptr, nullptr, reset_flags, last_reset, 0, 0, 0.0, traj,
+                          nullptr, nullptr, 0, -1, /*inv_tables=*/true);
 }
 
 int ml2048_rollout_fast(void *stream, int64_t M, int64_t idx_base, const ml2048_state *st, int32_t N,

@@ -1158,6 +1158,7 @@ class VecGame:
         fast = self._spawn != "table"
         on_device = (not fast) and self._schedule_mode == "device"
         dev_expanded = False
+        cur_inv = False  # the host schedule's tables are on the device as expanded rows
         if on_device:
             plain = trajectory is None and not record_actions and not digests
             perm_dev, sched_dev, mask_dev, E, dev_expanded = self._device_schedule(N, expanded=plain)
@@ -1178,7 +1179,10 @@ class VecGame:
             cur = self._la if asyn else None
             self._la = None
             staged = []  # pinned slots read by this rollout's launches: released by its event
-            expand = asyn and plain
+            # (round 3: a trajectory-writing rollout reads expanded tables too - ml2048_rollout_traj_expanded; only the
+            # chained upload of the NEXT schedule stays with the pipelined plain form)
+            expand = (asyn and plain) or (trajectory is not None and os.environ.get("ML2048_TRAJ_EXPANDED", "1") != "0")
+            chain_next = asyn and plain
 
             def dev_layout(E, o_mask, o_tab, nbytes):
                 # device copy: [schedule | masks | tables], the tables as 48-byte expanded rows when `expand`
@@ -1206,7 +1210,7 @@ class VecGame:
                 E, o_mask, o_tab = cur["E"], cur["o_mask"], cur["o_tab"]
                 packed_dev = self._sdev[cur["idx"]]
                 chain = None
-                if expand:
+                if chain_next:
                     # take the next schedule now and let this launch upload (and expand) it
                     nslot, lay2, after_next = self._take_schedule(N)
                     nxt = dev_layout(*lay2)
@@ -1223,6 +1227,7 @@ class VecGame:
                 return self._rollout_plain_chain(N, masked, act_seed, act_counter, finish_ids, kernel_timer,
                                                  packed_dev.data_ptr(), o_mask, o_tab, E, chain, staged)
             perm_dev = packed_dev[o_tab:cur["nbytes"]]
+            cur_inv = bool(cur["inv"])
             sched_dev = packed_dev[:N * 12]
             mask_dev = packed_dev[o_mask:o_mask + E * 4]
 
@@ -1259,7 +1264,7 @@ class VecGame:
                     assert buf.is_contiguous() and buf.dtype == dt and buf.device == dev and \
                         tuple(buf.shape[:2]) == (N, M), (name, buf.dtype, tuple(buf.shape))
                     setattr(tr, name, buf.data_ptr())
-                _lib.check(L.ml2048_rollout_traj(
+                _lib.check((L.ml2048_rollout_traj_expanded if cur_inv else L.ml2048_rollout_traj)(
                     self._stream(join=False), M, self._idx_base, self._st(), N, perm_dev.data_ptr(), mask_dev.data_ptr(),
                     E, sched_dev.data_ptr(), self._reward_kind, int(masked), int(act_seed), int(act_counter),
                     flags.data_ptr(), last.data_ptr(), C.byref(tr)), "rollout_traj")
