@@ -142,3 +142,17 @@ def test_take_copies_the_slot_layout():
             assert rs.value == ref.rand_step
     finally:
         L.ml2048_sched_stream_destroy(h)
+
+
+def test_stream_with_the_scalar_generator_too():
+    """The stream's PCG64 outputs come from an AVX-512 routine where the CPU has it (csrc/hostrng.cpp gen_outputs_avx512);
+    ML2048_HOSTRNG_AVX512=0 selects the scalar four-lane form.  The choice is made once per process, so the scalar form is
+    checked in a child process: the same stream-vs-synchronous comparison as above."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, ML2048_HOSTRNG_AVX512="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k", "delivers_the_same_schedules or after_states"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
