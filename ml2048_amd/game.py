@@ -383,6 +383,10 @@ class VecGame:
                 prev, scratch = self._lazy_scan, None
             elif not finish_ids:
                 scratch = None
+            elif self._ids_pending:
+                # an inline scan behind deferred ones: the older rollouts' games are numbered first (their scans go onto
+                # the launch stream / are waited for now, in front of this rollout's kernel and its scan)
+                self.join_ids()
             if kernel_timer is not None:
                 _lib.check(L.ml2048_timer_arm(kernel_timer), "timer_arm")
             if self._lut_ptr:

@@ -448,6 +448,24 @@ def test_runner_step_many_fuses_random_rollouts(amd):
     assert a.digest() == b.digest()
 
 
+@pytest.mark.parametrize("mode", ["host-async", "host"])
+def test_deferred_and_inline_id_scans_mixed(amd, mode):
+    """Deferred and inline id scans in any order number the games as all-inline scans do (the pipelined plain rollout
+    issues a deferred scan lazily: an inline one behind it must not overtake it)."""
+    M = 8192
+    a = amd.VecGame(M, "normal", schedule=mode)
+    b = amd.VecGame(M, "normal", schedule=mode)
+    a.reset(5)
+    b.reset(5)
+    c = 0
+    for fin in ["deferred", True, "deferred", "deferred", True, True, "deferred", False, "deferred", True]:
+        a.rollout(100, masked=False, act_seed=3, act_counter=c, finish_ids=fin)
+        b.rollout(100, masked=False, act_seed=3, act_counter=c, finish_ids=True if fin else False)
+        c += 100
+    assert np.array_equal(a.game_id.cpu().numpy(), b.game_id.cpu().numpy())
+    assert a._game_count == b._game_count and a._data.tobytes() == b._data.tobytes()
+
+
 def test_deferred_id_scan_equals_inline(amd):
     """rollout(finish_ids="deferred") (id scan on a side stream, overlapped with the next rollout) leaves
     the same ids, game counter, per-step re-deal counts and records as the inline scan - also when the
