@@ -52,21 +52,24 @@ while time.time() - t0 < budget:
             # with the id scan inline or deferred, sometimes with per-step digests (drops the look-ahead)
             n = last_n if rng.random() < 0.5 else int(rng.choice([1, 2, 7, 33, 64, 128, 200]))
             last_n = n
-            fin = "deferred" if rng.random() < 0.5 else True
-            dig = rng.random() < 0.15
-            outs = {}
-            for m, e in envs.items():
-                outs[m] = e.rollout(n, masked=masked, act_seed=5, act_counter=counter, finish_ids=fin, digests=dig)
-            if dig:
-                d0 = outs["host"]["digests"].cpu().numpy()
-                for m in outs:
-                    assert np.array_equal(outs[m]["digests"].cpu().numpy(), d0), (rounds, ops, m, "digests")
-            for _ in range(n):
-                step_env.prepare_torch()
-                pol.counter = counter
-                a, _ = pol.sample_actions_u8(step_env.valid_actions)
-                step_env.step_torch(a)
-                counter += 1
+            # one to three rollouts back to back, each with its own id-scan mode and nothing that joins in between (a
+            # deferred scan is issued lazily: the next rollout's own scan - inline or deferred - must not overtake it)
+            for _rep in range(int(rng.choice([1, 1, 2, 3]))):
+                fin = "deferred" if rng.random() < 0.5 else True
+                dig = rng.random() < 0.15
+                outs = {}
+                for m, e in envs.items():
+                    outs[m] = e.rollout(n, masked=masked, act_seed=5, act_counter=counter, finish_ids=fin, digests=dig)
+                if dig:
+                    d0 = outs["host"]["digests"].cpu().numpy()
+                    for m in outs:
+                        assert np.array_equal(outs[m]["digests"].cpu().numpy(), d0), (rounds, ops, m, "digests")
+                for _ in range(n):
+                    step_env.prepare_torch()
+                    pol.counter = counter
+                    a, _ = pol.sample_actions_u8(step_env.valid_actions)
+                    step_env.step_torch(a)
+                    counter += 1
         elif op < 8:  # per-step pair on everyone with explicit actions
             a = rng.integers(0, 4, size=M).astype(np.uint8)
             for e in list(envs.values()) + [step_env]:
