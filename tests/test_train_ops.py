@@ -123,6 +123,37 @@ def test_fused_trajectory_equals_stepwise_recording(masked, M, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["normal", "rank", "maxcell"])
+@pytest.mark.parametrize("expanded", ["1", "0"])
+def test_fused_trajectory_every_reward_kind_and_table_layout(kind, expanded, monkeypatch):
+    """The trajectory-writing rollout for the other reward functions, on expanded tables (dot-product spawn, re-deal and
+    spawned tile by LDS look-ups: ml2048_rollout_traj_expanded) and on plain ones (ML2048_TRAJ_EXPANDED=0), against
+    per-step recording."""
+    import ml2048_amd as amd
+    from ml2048_amd import train_ops
+
+    monkeypatch.setenv("ML2048_TRAJ_EXPANDED", expanded)
+    M, N = 3000, 150   # long enough for games to end and be re-dealt inside the rollout
+    a = amd.VecGame(M, kind)
+    b = amd.VecGame(M, kind)
+    a.reset(33)
+    b.reset(33)
+    traj = train_ops.new_buffers((N, M), a.device, spec=train_ops.REPLAY_SPEC)
+    a.rollout(N, masked=True, act_seed=8, act_counter=7, trajectory=traj)
+    ref = train_ops.new_buffers((1, N, M), b.device, spec=train_ops.REPLAY_SPEC)
+    pol = amd.RandomPolicy(seed=8, masked=True)
+    pol.counter = 7
+    for t in range(N):
+        b.prepare_torch()
+        act, lp = pol.sample_actions_u8(b.valid_actions)
+        b.step_torch(act)
+        train_ops.record_transition(b, act, lp, ref, 0, t)
+    for k in train_ops.REPLAY_SPEC:
+        assert torch.equal(traj[k].view(torch.uint8), ref[k][0].view(torch.uint8)), k
+    assert a._data.tobytes() == b._data.tobytes() and a._game_count == b._game_count and a._game_count > M
+
+
+@pytest.mark.gpu
 def test_fused_trajectory_with_missing_fields():
     """Any subset of the REPLAY_SPEC fields may be requested (NULL pointers are skipped)."""
     import ml2048_amd as amd
