@@ -242,6 +242,10 @@ def rollout_roofline(M: int, N: int, avg_ms: float, masked: bool, traj: bool, sp
             r["valu_pipe_note"] = (f"{valu} vector instructions per wave-step x {waves / N_SIMD:.2f} waves per SIMD x "
                                    f"{per_inst_ns:.3f} ns per instruction of this loop's mix on a busy SIMD "
                                    f"(profiles/valu_mix.json, {costs.get('source')}) / the step's duration")
+        r["frac_note"] = ("frac = vector instructions issued per second / the chip's 2-cycle VALU peak: it FALLS when work is "
+                          "removed (round 2's kernel issued 211 VALU per wave-step in 68 us: 0.31; this one 171 in 65 us), and "
+                          "half of the mix issues at half rate on gfx950 (profiles/valu_issue_costs.json) - lone_wave_frac "
+                          "(one wave per SIMD) / valu_pipe_busy_frac (several) price the kernel's time at the measured costs")
         assert r["frac"] <= 1.0, r
     else:
         r.update({"achieved": None, "frac": None, "insts_per_wave_step": None,
