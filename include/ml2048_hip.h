@@ -318,6 +318,9 @@ int64_t ml2048_rollout_scratch_ints(int64_t M, int32_t N);
  * by the calling thread (hipExtLaunchKernel start/stop events), i.e. the kernel's own duration as
  * rocprofv3 reports it, without the marker packets that events recorded around a launch add.
  * create -> arm (one-shot) -> launch -> elapsed_ms (synchronises on the stop event) -> destroy.
+ * The thread's one-shots (this one, ml2048_rollout_attach_event, ml2048_rollout_attach_row_lut) are spent by the next
+ * ml2048_rollout* call whether it launches or fails an argument check: none stays armed for a later, unrelated launch
+ * (elapsed_ms of a timer that never rode on a launch is an error).
  */
 int ml2048_timer_create(void **timer);
 int ml2048_timer_arm(void *timer);

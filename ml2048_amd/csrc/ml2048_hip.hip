@@ -1902,6 +1902,16 @@ static thread_local ml2048_timer_impl *g_armed_timer = nullptr;
 static thread_local hipEvent_t g_attach_stop_event = nullptr;
 static thread_local const uint16_t *g_attach_row_lut = nullptr; // one-shot: the next rollout launch's line table
 static thread_local bool g_stop_event_attached = false;
+// Every public rollout entry point holds one of these: whatever the call does - launch, or fail an argument check before
+// it gets that far - the thread's one-shots (armed timer, attached marker event, attached line table) are spent when it
+// returns, so none of them can ride on an unrelated later launch.
+struct rollout_one_shots {
+    ~rollout_one_shots() {
+        g_armed_timer = nullptr;
+        g_attach_stop_event = nullptr;
+        g_attach_row_lut = nullptr;
+    }
+};
 
 int ml2048_timer_create(void **timer) {
     if (!timer) return fail(ML2048_E_INVALID, "timer is NULL");
@@ -1992,6 +2002,15 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
                           const void *up_src = nullptr, void *up_dst = nullptr, int64_t up_nbytes = 0,
                           int64_t up_table_offset = -1, bool inv_tables = false, const uint16_t *row_lut = nullptr) {
     ml2048_traj traj = {};
+    // the per-thread one-shots (armed timer, attached marker event, attached line table) belong to THIS call whether it
+    // launches or fails its checks: none of them may stay armed for an unrelated later launch
+    ml2048_timer_impl *const timer = g_armed_timer;
+    g_armed_timer = nullptr;
+    const hipEvent_t attached_event = g_attach_stop_event;
+    g_attach_stop_event = nullptr;
+    g_stop_event_attached = false;
+    if (!row_lut) row_lut = g_attach_row_lut;
+    g_attach_row_lut = nullptr;
     if (up_table_offset < 0) up_table_offset = up_nbytes; // no table units: a plain copy
     if (up_table_offset > up_nbytes || (up_table_offset < up_nbytes && (up_table_offset % 16 || (up_nbytes - up_table_offset) % 16)))
         return fail(ML2048_E_INVALID, "next_table_offset=%lld", (long long)up_table_offset);
@@ -2001,8 +2020,6 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
     }
     const int64_t up_n16 = (up_nbytes + 15) / 16;
     const int64_t up_tab16 = up_table_offset >= up_nbytes ? up_n16 : up_table_offset / 16;
-    if (!row_lut) row_lut = g_attach_row_lut;
-    g_attach_row_lut = nullptr;
     if ((uintptr_t)row_lut % 16) return fail(ML2048_E_ALIGN, "row_lut must be 16-byte aligned");
     if (traj_or_null) {
         traj = *traj_or_null;
@@ -2016,16 +2033,13 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
     const int64_t W = ml2048_rollout_flag_words(M);
     const uint64_t thr = two_threshold(two_prob);
     const bool extras = actions_out || digests_out || traj_or_null;
-    ml2048_timer_impl *const timer = g_armed_timer; // one-shot: bracket THIS dispatch with the armed timer's events
-    g_armed_timer = nullptr;
+    // an armed timer brackets THIS dispatch with its events
     hipEvent_t ev_start = timer ? timer->start : nullptr, ev_stop = timer ? timer->stop : nullptr;
     if (timer) timer->used = true;
-    g_stop_event_attached = false;
-    if (!timer && g_attach_stop_event) { // (a timed dispatch keeps its own pair: the caller records the marker then)
-        ev_stop = g_attach_stop_event;
+    if (!timer && attached_event) { // (a timed dispatch keeps its own pair: the caller records the marker then)
+        ev_stop = attached_event;
         g_stop_event_attached = true;
     }
-    g_attach_stop_event = nullptr;
     if (inv_tables && fast) return fail(ML2048_E_UNSUPPORTED, "expanded tables: table-mode rollouts only");
     if (extras && up_n16 > 0) return fail(ML2048_E_UNSUPPORTED, "chained upload: plain rollouts only");
     if (!extras) { // the plain instantiations live in their own compilation passes (see ml2048_plain_launch)
@@ -2092,6 +2106,7 @@ int ml2048_rollout(void *stream, int64_t M, int64_t idx_base, const ml2048_state
                    const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,
                    const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0,
                    uint8_t *actions_out, uint64_t *digests_out, uint64_t *reset_flags, int32_t *last_reset) {
+    const rollout_one_shots spent_on_return;
     if (int rc = check_state(M, st)) return rc;
     if (N <= 0 || n_epochs <= 0) return fail(ML2048_E_INVALID, "N=%d n_epochs=%d must be positive", N, n_epochs);
     if (!perm_epochs || !two_masks || !schedule || !reset_flags || !last_reset)
@@ -2108,6 +2123,7 @@ int ml2048_rollout_chain(void *stream, int64_t M, int64_t idx_base, const ml2048
                          const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0,
                          uint64_t *reset_flags, int32_t *last_reset, const void *next_src_host, void *next_dst,
                          int64_t next_nbytes, int64_t next_table_offset) {
+    const rollout_one_shots spent_on_return;
     if (int rc = check_state(M, st)) return rc;
     if (N <= 0 || n_epochs <= 0) return fail(ML2048_E_INVALID, "N=%d n_epochs=%d must be positive", N, n_epochs);
     if (!perm_epochs || !two_masks || !schedule || !reset_flags || !last_reset)
@@ -2123,6 +2139,7 @@ int ml2048_rollout_traj(void *stream, int64_t M, int64_t idx_base, const ml2048_
                         const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,
                         const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0,
                         uint64_t *reset_flags, int32_t *last_reset, const ml2048_traj *traj) {
+    const rollout_one_shots spent_on_return;
     if (int rc = check_state(M, st)) return rc;
     if (N <= 0 || n_epochs <= 0) return fail(ML2048_E_INVALID, "N=%d n_epochs=%d must be positive", N, n_epochs);
     if (!perm_epochs || !two_masks || !schedule || !reset_flags || !last_reset || !traj)
@@ -2137,6 +2154,7 @@ int ml2048_rollout_traj_expanded(void *stream, int64_t M, int64_t idx_base, cons
                                  const uint8_t *perm_epochs, const uint32_t *two_masks, int32_t n_epochs,
                                  const int32_t *schedule, int reward_kind, int masked, uint64_t act_seed, uint64_t act_counter0,
                                  uint64_t *reset_flags, int32_t *last_reset, const ml2048_traj *traj) {
+    const rollout_one_shots spent_on_return;
     if (int rc = check_state(M, st)) return rc;
     if (N <= 0 || n_epochs <= 0) return fail(ML2048_E_INVALID, "N=%d n_epochs=%d must be positive", N, n_epochs);
     if (!perm_epochs || !two_masks || !schedule || !reset_flags || !last_reset || !traj)
@@ -2152,6 +2170,7 @@ int ml2048_rollout_fast(void *stream, int64_t M, int64_t idx_base, const ml2048_
                         double two_prob, uint64_t spawn_seed, uint64_t spawn_counter0, int reward_kind, int masked,
                         uint64_t act_seed, uint64_t act_counter0, uint8_t *actions_out, uint64_t *digests_out,
                         uint64_t *reset_flags, int32_t *last_reset) {
+    const rollout_one_shots spent_on_return;
     if (int rc = check_state(M, st)) return rc;
     if (N <= 0) return fail(ML2048_E_INVALID, "N=%d must be positive", N);
     if (!reset_flags || !last_reset) return fail(ML2048_E_INVALID, "reset_flags/last_reset is NULL");
@@ -2265,6 +2284,7 @@ int ml2048_rollout_chain_ids(void *stream, int64_t M, int64_t idx_base, const ml
                              uint64_t *reset_flags, int32_t *last_reset, const void *next_src_host, void *next_dst,
                              int64_t next_nbytes, int64_t next_table_offset, void *rollout_event, void *ids_stream,
                              int32_t *game_count, int32_t *step_resets, int32_t *scratch, void *ids_done_event) {
+    const rollout_one_shots spent_on_return;
     const bool ids = scratch != nullptr;
     if (ids && ids_stream != stream && !rollout_event)
         return fail(ML2048_E_INVALID, "an id scan on another stream needs rollout_event to wait for");

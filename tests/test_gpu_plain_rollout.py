@@ -248,3 +248,32 @@ def test_plain_rollout_on_states_outside_the_score_guard(amd, oracle):
         ref.step(a)
     _assert_same(env, ref, "states outside the score guard")
     assert env._game_count == ref._game_count
+
+
+def test_a_failed_rollout_call_spends_the_threads_one_shots(amd):
+    """ml2048_timer_arm / ml2048_rollout_attach_event / ml2048_rollout_attach_row_lut are one-shots of the calling thread for
+    "the next rollout launch".  A rollout call that fails an argument check is that next call: nothing may stay armed and ride
+    on an unrelated later launch (include/ml2048_hip.h: the one-shot notes)."""
+    import ctypes as C
+
+    L = amd._lib.load()
+    env = amd.VecGame(4096, amd.reward_fn_normal, device="cuda:0", schedule="host-async")
+    env.reset(3)
+    tm = C.c_void_p()
+    amd._lib.check(L.ml2048_timer_create(C.byref(tm)), "timer_create")
+    try:
+        amd._lib.check(L.ml2048_timer_arm(tm), "timer_arm")
+        # N = 0 fails the entry check before anything is launched
+        rc = L.ml2048_rollout_chain(None, 4096, 0, env._st(), 0, None, None, 1, None, 0, 0, 0, 0, None, None, None, None, 0, 0)
+        assert rc == -1 and b"N=0" in L.ml2048_last_error()
+        env.rollout(16, masked=False, act_seed=1)  # an unrelated launch of the same thread
+        env.join_ids()
+        ms = C.c_float(-1.0)
+        assert L.ml2048_timer_elapsed_ms(tm, C.byref(ms)) == -1 and b"never attached" in L.ml2048_last_error()
+        # and armed again, the timer does bracket the next launch
+        env.rollout(16, masked=False, act_seed=1, act_counter=16, kernel_timer=tm)
+        env.join_ids()
+        amd._lib.check(L.ml2048_timer_elapsed_ms(tm, C.byref(ms)), "timer_elapsed_ms")
+        assert 0.0 < ms.value < 50.0
+    finally:
+        L.ml2048_timer_destroy(tm)
