@@ -20,8 +20,8 @@ The JSON line also carries
   cpu_baseline  the CPU oracle (a bit-exact C/OpenMP restatement of the reference, "port") timed
                 on this host on a bounded sample of the same workload (rank 0, N=1 only)
   extras        (rank 0, N=1, default mode) the same C2 workload one launch per env step, C3 (M=262144, masked
-                sampling + one-hot observation per env step), the fused rollout at C4's per-GPU shard size, and the
-                rocRAND spawn mode
+                sampling + one-hot observation per env step), the fused rollout at C4's per-GPU shard size, the
+                rocRAND spawn mode, and the C2 rollout with actions drawn over the valid actions only
 """
 from __future__ import annotations
 
@@ -497,6 +497,17 @@ def main():
                                                 "tile, one Philox block per four steps), no host schedule; not bit-exact "
                                                 "with the numba path, the same game statistically (see DESIGN.md)"}
         del sfn, _e
+        # (5) the fused C2 workload with the reference RandomPolicy's masking (policy/random.py:17-27: uniform over the
+        # VALID actions; the headline draws unmasked uniform actions as SURVEY 8c defines C2) - bit-exact spawn mode
+        if not masked:
+            sfn, stm, _e = make_fused(M, N, True, "fused", args.schedule, seed_off=500)
+            d1 = measure(sfn, 200, 20, finish=_e.join_ids)
+            ms1 = timers_avg_ms(stm)
+            extras["masked_actions"] = {"value": M * N * 200 / d1, "unit": "board-steps/s", "ms_per_step": d1 / 200 * 1e3,
+                                        "workload": f"M={M} x N={N} fused rollout, actions uniform over each board's valid "
+                                                    "actions (the reference RandomPolicy's sampling rule), table spawn",
+                                        "roofline": rollout_roofline(M, N, ms1, True, False)}
+            del sfn, _e
         args.event_every = saved_every
 
     cpu = None
