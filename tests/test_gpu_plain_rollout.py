@@ -109,6 +109,18 @@ def test_plain_chain_matrix(amd, oracle, M, lengths, reward, counter0):
     _run(amd, oracle, M, lengths, reward, "host-async", counter0, ids="deferred" if M % 2 == 0 else "inline")
 
 
+@pytest.mark.parametrize("M,lengths,reward,counter0", [
+    (1, [64, 63, 1], "normal", 0),             # one board; the small-M pass takes the line table from 64 steps on
+    (64, [64], "improved", 15),                # exactly one full wave
+    (65, [63, 64, 65], "rank", 2),             # a full wave and a one-lane wave, around the table's step threshold
+    (70000, [16, 15, 17], "normal", 63),       # the large-M pass takes the table from 16 steps on
+])
+def test_plain_chain_at_the_table_thresholds(amd, oracle, M, lengths, reward, counter0):
+    """Launches just below and at the step counts from which a pass is given the LDS line table (launch_rollout: N >= 64 in
+    the small-M passes, N >= 16 in the large-M pass), at the smallest board counts."""
+    _run(amd, oracle, M, lengths, reward, "host-async", counter0, ids="deferred")
+
+
 def test_plain_2m_boards_large_pass(amd, oracle):
     """BASELINE config 4's total size as one plain rollout (large-M pass, 32 768 wavefronts)."""
     _run(amd, oracle, 2097152, [128], "normal", "host-async", 1)
