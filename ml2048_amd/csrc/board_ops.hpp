@@ -84,6 +84,22 @@ ML_HD Board transpose(const Board &b) {
     return t;
 }
 
+// The transposition OR the identity, chosen per lane by the two byte selectors alone: pairing the rows (0, 2) and (1, 3)
+// in the first stage lets the same eight v_perm_b32 do either - (sx, sy) = (0x05010400, 0x07030602) transposes,
+// (0x03020100, 0x07060504) hands the board back.  `if (horizontal) b = transpose(b)` costs a wave the exec-mask round
+// trip and four v_mov for the lanes that keep their board; this form costs two selects per step, off the board's
+// dependency chain (the selectors only depend on the action).
+ML_HD Board transpose_by(const Board &b, uint32_t sx, uint32_t sy) {
+    const uint32_t t0 = perm_b32(b.r[2], b.r[0], sx), t1 = perm_b32(b.r[2], b.r[0], sy);
+    const uint32_t t2 = perm_b32(b.r[3], b.r[1], sx), t3 = perm_b32(b.r[3], b.r[1], sy);
+    Board o;
+    o.r[0] = perm_b32(t2, t0, sx);
+    o.r[1] = perm_b32(t2, t0, sy);
+    o.r[2] = perm_b32(t3, t1, sx);
+    o.r[3] = perm_b32(t3, t1, sy);
+    return o;
+}
+
 // ---- one line, pushed toward byte 0 (reference _push_row, game_numba.py:48-90) ---------------
 // Returns the new line; mexp gets the pre-merge exponents of the (at most two) merges in
 // bytes 0 and 1 (0 = no merge): exactly the indices `buckets[num] += 1` touches (:76).
@@ -265,8 +281,13 @@ template <bool SWZ = false, class LutPtr>
 ML_HD Board move_board_lut(const Board &in, uint32_t action, LutPtr lut) {
     const bool horizontal = (action & 2u) == 0;
     const bool reverse = (action & 1u) != 0;
+#if !defined(ML2048_TRANSPOSE_BY) || ML2048_TRANSPOSE_BY // (-DML2048_TRANSPOSE_BY=0: the exec-masked transposes, A/B)
+    const uint32_t tsx = horizontal ? 0x05010400u : 0x03020100u, tsy = horizontal ? 0x07030602u : 0x07060504u;
+    Board b = transpose_by(in, tsx, tsy);
+#else
     Board b = in;
     if (horizontal) b = transpose(b);
+#endif
     const uint32_t a = reverse ? b.r[3] : b.r[0], bb = reverse ? b.r[2] : b.r[1];
     const uint32_t c = reverse ? b.r[1] : b.r[2], d = reverse ? b.r[0] : b.r[3];
     // byte j of n01 / n23 = the low / high byte of line j's index (row_lut_slot on all four lines at once)
@@ -285,8 +306,12 @@ ML_HD Board move_board_lut(const Board &in, uint32_t action, LutPtr lut) {
     b.r[1] = reverse ? o2 : o1;
     b.r[2] = reverse ? o1 : o2;
     b.r[3] = reverse ? o0 : o3;
+#if !defined(ML2048_TRANSPOSE_BY) || ML2048_TRANSPOSE_BY
+    return transpose_by(b, tsx, tsy);
+#else
     if (horizontal) b = transpose(b);
     return b;
+#endif
 }
 
 // every tile <= 2^11 and at most 8 191 steps ahead: the tile sum (<= 16 * 2048 now, + 4 per step at most) stays below
