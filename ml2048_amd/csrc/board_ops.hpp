@@ -100,6 +100,33 @@ ML_HD Board transpose_by(const Board &b, uint32_t sx, uint32_t sy) {
     return o;
 }
 
+// The same network with a selector pair per stage does the whole orientation of a move - transpose for a horizontal
+// move AND the reversal of the cell order for a move toward the far side - and its inverse (checked for every action by
+// tests/test_host_ops.py): vertical moves reverse by swapping which source word a selector byte names (^ 0x04 in both
+// stages), horizontal ones by reversing the byte order the first stage reads (^ 0x03) or the second stage of the
+// inverse writes (^ 0x05).  s[0..1] / s[2..3]: stage 1 / 2 of the forward network; s[2..3] / s[4..5]: of the inverse.
+ML_HD void move_selectors(uint32_t action, uint32_t s[6]) {
+    const bool horizontal = (action & 2u) == 0;
+    const uint32_t rev = (action & 1u) ? 0xFFFFFFFFu : 0u;
+    const uint32_t sx = horizontal ? 0x05010400u : 0x03020100u, sy = horizontal ? 0x07030602u : 0x07060504u;
+    const uint32_t m_a = rev & (horizontal ? 0x03030303u : 0x04040404u);
+    const uint32_t m_b = rev & (horizontal ? 0u : 0x04040404u);
+    const uint32_t m_d = rev & (horizontal ? 0x05050505u : 0x04040404u);
+    s[0] = sx ^ m_a; s[1] = sy ^ m_a;
+    s[2] = sx ^ m_b; s[3] = sy ^ m_b;
+    s[4] = sx ^ m_d; s[5] = sy ^ m_d;
+}
+ML_HD Board perm_net(const Board &b, uint32_t s1x, uint32_t s1y, uint32_t s2x, uint32_t s2y) {
+    const uint32_t t0 = perm_b32(b.r[2], b.r[0], s1x), t1 = perm_b32(b.r[2], b.r[0], s1y);
+    const uint32_t t2 = perm_b32(b.r[3], b.r[1], s1x), t3 = perm_b32(b.r[3], b.r[1], s1y);
+    Board o;
+    o.r[0] = perm_b32(t2, t0, s2x);
+    o.r[1] = perm_b32(t2, t0, s2y);
+    o.r[2] = perm_b32(t3, t1, s2x);
+    o.r[3] = perm_b32(t3, t1, s2y);
+    return o;
+}
+
 // ---- one line, pushed toward byte 0 (reference _push_row, game_numba.py:48-90) ---------------
 // Returns the new line; mexp gets the pre-merge exponents of the (at most two) merges in
 // bytes 0 and 1 (0 = no merge): exactly the indices `buckets[num] += 1` touches (:76).
@@ -312,6 +339,31 @@ ML_HD Board move_board_lut(const Board &in, uint32_t action, LutPtr lut) {
     if (horizontal) b = transpose(b);
     return b;
 #endif
+}
+
+// move_board_lut with the orientation folded into the byte selectors: `sel` = a table of move_selectors(action) at
+// sel[8 * action .. 8 * action + 5] (the rollout kernel keeps it in LDS: two look-ups per step replace the direction
+// decode, the two selects of transpose_by's selectors and the eight selects of the cell-order reversal)
+template <bool SWZ = false, class LutPtr, class SelPtr>
+ML_HD Board move_board_lut_sel(const Board &in, uint32_t action, LutPtr lut, SelPtr sel) {
+    const uint32_t *sp = &sel[8u * (action & 3u)];
+    const uint32_t s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4], s5 = sp[5];
+    const Board b = perm_net(in, s0, s1, s2, s3);
+    const uint32_t n23 = b.r[2] | (b.r[3] << 4);
+    const uint32_t n01 = SWZ ? (b.r[0] | (b.r[1] << 4)) ^ ((n23 << 2) & 0xFCFCFCFCu) : b.r[0] | (b.r[1] << 4);
+    const uint32_t r0 = lut[perm_b32(n23, n01, 0x0c0c0400u)];
+    const uint32_t r1 = lut[perm_b32(n23, n01, 0x0c0c0501u)];
+    const uint32_t r2 = lut[perm_b32(n23, n01, 0x0c0c0602u)];
+    const uint32_t r3 = lut[perm_b32(n23, n01, 0x0c0c0703u)];
+    const uint32_t r01 = r0 | (r1 << 16), r23 = r2 | (r3 << 16);
+    const uint32_t e = perm_b32(r23, r01, 0x06040200u);
+    const uint32_t f = perm_b32(r23, r01, 0x07050301u);
+    Board o;
+    o.r[0] = e & 0x0F0F0F0Fu;
+    o.r[1] = (e >> 4) & 0x0F0F0F0Fu;
+    o.r[2] = f & 0x0F0F0F0Fu;
+    o.r[3] = (f >> 4) & 0x0F0F0F0Fu;
+    return perm_net(o, s2, s3, s4, s5);
 }
 
 // every tile <= 2^11 and at most 8 191 steps ahead: the tile sum (<= 16 * 2048 now, + 4 per step at most) stays below
@@ -902,6 +954,27 @@ ML_HD bool step_pre_lazy_pv_lut(StepRegs &s, uint32_t action, Board &pv, uint32_
     pv = prev;
     pv_action = action;
     s.board = nb;
+    s.step += 1;
+    return true;
+}
+template <bool SWZ = false, class LutPtr, class SelPtr>
+ML_HD bool step_pre_lazy_pv_lut(StepRegs &s, uint32_t action, Board &pv, uint32_t &pv_action, LutPtr lut, SelPtr sel) {
+    const Board prev = s.board;
+    const Board nb = move_board_lut_sel<SWZ>(prev, action, lut, sel);
+    if (action >= 4u || !board_differs(nb, prev)) return false;
+    pv = prev;
+    pv_action = action;
+    s.board = nb;
+    s.step += 1;
+    return true;
+}
+template <bool SWZ = false, class LutPtr, class SelPtr>
+ML_HD bool step_pre_lite_pv_lut(StepRegs &s, uint32_t action, Board &pv, uint32_t &pv_action, LutPtr lut, SelPtr sel) {
+    const bool ok = action < 4u && ((s.valid >> (8u * (action & 3u))) & 0xFFu) != 0u;
+    if (!ok) return false;
+    pv = s.board;
+    pv_action = action;
+    s.board = move_board_lut_sel<SWZ>(pv, action, lut, sel);
     s.step += 1;
     return true;
 }

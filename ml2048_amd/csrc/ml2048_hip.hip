@@ -863,6 +863,26 @@ __global__ __launch_bounds__(EXTRAS ? kBlock : kRollMaxBlock) void k_rollout(ml2
     constexpr bool TILE_LDS = false;
 #endif
     __shared__ uint4 tile_s[TILE_LDS ? 32 : 1];
+    // ... and the orientation of the table move as byte selectors looked up by the action (board_ops.hpp move_selectors)
+    // (where waves share a SIMD: 262 144 boards 147.3 -> 142.0 us; a lone wave gains nothing - C2 65.2-66.3 vs 65.6-65.9 us,
+    // rocRAND mode 80.0 vs 79.4 - so the small-M passes keep the decoded form.  -DML2048_MOVE_SEL=0 / =1: off / on
+    // in every pass, A/B)
+#if !defined(ML2048_MOVE_SEL)
+    constexpr bool MOVE_SEL = HAS_LUT && !LUT_SWZ;
+#elif ML2048_MOVE_SEL
+    constexpr bool MOVE_SEL = HAS_LUT;
+#else
+    constexpr bool MOVE_SEL = false;
+#endif
+    __shared__ __attribute__((aligned(32))) uint32_t msel_s[MOVE_SEL ? 32 : 8];
+    if constexpr (MOVE_SEL) {
+        if (threadIdx.x < 32) {
+            uint32_t sel6[6];
+            move_selectors(threadIdx.x >> 3, sel6);
+            const uint32_t k = threadIdx.x & 7u;
+            msel_s[threadIdx.x] = k == 0 ? sel6[0] : k == 1 ? sel6[1] : k == 2 ? sel6[2] : k == 3 ? sel6[3] : k == 4 ? sel6[4] : k == 5 ? sel6[5] : 0u;
+        }
+    }
     if constexpr (TILE_LDS) {
         if (threadIdx.x < 32) {
             const uint32_t c = threadIdx.x & 15u, v = 2u - (threadIdx.x >> 4);
@@ -910,7 +930,7 @@ __global__ __launch_bounds__(EXTRAS ? kBlock : kRollMaxBlock) void k_rollout(ml2
             for (; k0 < kUnits; k0 += nthr) put(k0, g[k0]);
         }
     }
-    if (DEAL_LDS || TILE_LDS || (HAS_LUT && row_lut)) __syncthreads();
+    if (DEAL_LDS || TILE_LDS || MOVE_SEL || (HAS_LUT && row_lut)) __syncthreads();
     if constexpr (!EXTRAS) {
         // Chained upload: this launch also copies the NEXT rollout's packed schedule from device-accessible
         // host memory into the other device buffer - ordered before the next launch by the stream itself,
@@ -1248,8 +1268,12 @@ __global__ __launch_bounds__(EXTRAS ? kBlock : kRollMaxBlock) void k_rollout(ml2
                 // ---- step (game_numba.py:660-738)
                 prev_board = s.board;
                 if (!LAZY) prev_valid = s.valid;
-                if (LAZY    ? (LUT ? step_pre_lazy_pv_lut<LUT_SWZ>(s, action, pv, pv_action, lut_s) : step_pre_lazy_pv(s, action, pv, pv_action))
-                    : DEFER ? (LUT ? step_pre_lite_pv_lut<LUT_SWZ>(s, action, pv, pv_action, lut_s) : step_pre_lite_pv(s, action, pv, pv_action))
+                if (LAZY    ? (LUT ? (MOVE_SEL ? step_pre_lazy_pv_lut<LUT_SWZ>(s, action, pv, pv_action, lut_s, msel_s)
+                                                : step_pre_lazy_pv_lut<LUT_SWZ>(s, action, pv, pv_action, lut_s))
+                                   : step_pre_lazy_pv(s, action, pv, pv_action))
+                    : DEFER ? (LUT ? (MOVE_SEL ? step_pre_lite_pv_lut<LUT_SWZ>(s, action, pv, pv_action, lut_s, msel_s)
+                                                : step_pre_lite_pv_lut<LUT_SWZ>(s, action, pv, pv_action, lut_s))
+                                   : step_pre_lite_pv(s, action, pv, pv_action))
                             : step_pre_lite(s, action, KIND, mexp_first, mexp_second)) {
                     merged_stale = true;
                     uint32_t empties = 0;

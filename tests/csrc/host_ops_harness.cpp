@@ -91,9 +91,11 @@ int64_t h_move_forms_check(const uint8_t *boards, int64_t n) {
 // in *skipped.  Also checks lut_guard: a board it accepts must be in the domain for every direction.
 int64_t h_move_lut_check(const uint8_t *boards, int64_t n, int64_t *skipped) {
     static uint16_t lut[kRowLutEntries], lut_swz[kRowLutEntries]; // plain and bank-swizzled layout (row_lut_slot)
+    static uint32_t sel[32];                                       // move_selectors(a) at sel[8 a ..] (the kernel's LDS table)
     static bool filled = false;
     if (!filled) {
         for (uint32_t i = 0; i < (uint32_t)kRowLutEntries; ++i) lut[i] = lut_swz[row_lut_slot(i)] = row_lut_entry(i);
+        for (uint32_t a = 0; a < 4; ++a) move_selectors(a, sel + 8 * a);
         filled = true;
     }
     int64_t bad = 0, skip = 0;
@@ -112,6 +114,9 @@ int64_t h_move_lut_check(const uint8_t *boards, int64_t n, int64_t *skipped) {
             }
             const Board y = move_board_lut<false>(b, a, lut), z = move_board_lut<true>(b, a, lut_swz);
             if (memcmp(x.board.r, y.r, 16) != 0 || memcmp(x.board.r, z.r, 16) != 0) ++bad;
+            // the same with the orientation folded into looked-up byte selectors
+            const Board ys = move_board_lut_sel<false>(b, a, lut, sel), zs = move_board_lut_sel<true>(b, a, lut_swz, sel);
+            if (memcmp(x.board.r, ys.r, 16) != 0 || memcmp(x.board.r, zs.r, 16) != 0) ++bad;
         }
     }
     *skipped = skip;
