@@ -295,7 +295,8 @@ int ml2048_devrng2_schedule(void *stream, void *workspace, ml2048_devrng *rng, u
  * (VecRunner.step_many with RandomPolicy, src/ml2048/runner.py:74-117, policy/random.py:17-27)
  * as ONE launch, every board resident in registers for all N steps; bit-exact with N calls of
  * ml2048_prepare / ml2048_sample_actions / ml2048_step on the same host RNG schedule.
- *   perm_epochs   device uint8[n_epochs][1024][16]: the successive `_randperm` tables
+ *   perm_epochs   device uint8[n_epochs][1024][16]: the successive `_randperm` tables (n_epochs <= 65536 per launch:
+ *                 rows are addressed by 32-bit byte offsets from this base; more is ML2048_E_INVALID)
  *   two_masks     device uint32[n_epochs]: bit c <=> float64(randfloat[c]) < two_prob (H1: only
  *                 randfloat[0..15] are ever read, game_numba.py:207)
  *   schedule      device int32[N][3]: {table epoch, row_base of prepare, row_base of step} - the

@@ -2065,6 +2065,8 @@ static int launch_rollout(hipStream_t s, bool fast, int64_t M, int64_t idx_base,
         g_stop_event_attached = true;
     }
     if (inv_tables && fast) return fail(ML2048_E_UNSUPPORTED, "expanded tables: table-mode rollouts only");
+    if (!fast && n_epochs > 65536) // (table rows are addressed by 32-bit byte offsets from the tables' base: 65 536 x 48 KiB < 4 GiB)
+        return fail(ML2048_E_INVALID, "n_epochs=%d: at most 65536 table epochs per launch", n_epochs);
     if (extras && up_n16 > 0) return fail(ML2048_E_UNSUPPORTED, "chained upload: plain rollouts only");
     if (!extras) { // the plain instantiations live in their own compilation passes (see ml2048_plain_launch)
         // one workgroup = one compute unit's share of the boards (the LDS line table leaves room for one workgroup per
