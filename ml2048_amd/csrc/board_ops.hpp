@@ -84,21 +84,23 @@ ML_HD Board transpose(const Board &b) {
     return t;
 }
 
-// The transposition OR the identity, chosen per lane by the two byte selectors alone: pairing the rows (0, 2) and (1, 3)
-// in the first stage lets the same eight v_perm_b32 do either - (sx, sy) = (0x05010400, 0x07030602) transposes,
-// (0x03020100, 0x07060504) hands the board back.  `if (horizontal) b = transpose(b)` costs a wave the exec-mask round
-// trip and four v_mov for the lanes that keep their board; this form costs two selects per step, off the board's
-// dependency chain (the selectors only depend on the action).
-ML_HD Board transpose_by(const Board &b, uint32_t sx, uint32_t sy) {
-    const uint32_t t0 = perm_b32(b.r[2], b.r[0], sx), t1 = perm_b32(b.r[2], b.r[0], sy);
-    const uint32_t t2 = perm_b32(b.r[3], b.r[1], sx), t3 = perm_b32(b.r[3], b.r[1], sy);
+// A two-stage network of eight v_perm_b32 that pairs the rows (0, 2) and (1, 3) in its first stage: what it does to the
+// board is decided by its byte selectors alone (a pair per stage), which may differ from lane to lane.
+ML_HD Board perm_net(const Board &b, uint32_t s1x, uint32_t s1y, uint32_t s2x, uint32_t s2y) {
+    const uint32_t t0 = perm_b32(b.r[2], b.r[0], s1x), t1 = perm_b32(b.r[2], b.r[0], s1y);
+    const uint32_t t2 = perm_b32(b.r[3], b.r[1], s1x), t3 = perm_b32(b.r[3], b.r[1], s1y);
     Board o;
-    o.r[0] = perm_b32(t2, t0, sx);
-    o.r[1] = perm_b32(t2, t0, sy);
-    o.r[2] = perm_b32(t3, t1, sx);
-    o.r[3] = perm_b32(t3, t1, sy);
+    o.r[0] = perm_b32(t2, t0, s2x);
+    o.r[1] = perm_b32(t2, t0, s2y);
+    o.r[2] = perm_b32(t3, t1, s2x);
+    o.r[3] = perm_b32(t3, t1, s2y);
     return o;
 }
+// The transposition OR the identity: (sx, sy) = (0x05010400, 0x07030602) in both stages transposes, (0x03020100,
+// 0x07060504) hands the board back.  `if (horizontal) b = transpose(b)` costs a wave the exec-mask round trip and four
+// v_mov for the lanes that keep their board; this form costs two selects per step, off the board's dependency chain
+// (the selectors only depend on the action).
+ML_HD Board transpose_by(const Board &b, uint32_t sx, uint32_t sy) { return perm_net(b, sx, sy, sx, sy); }
 
 // The same network with a selector pair per stage does the whole orientation of a move - transpose for a horizontal
 // move AND the reversal of the cell order for a move toward the far side - and its inverse (checked for every action by
@@ -115,16 +117,6 @@ ML_HD void move_selectors(uint32_t action, uint32_t s[6]) {
     s[0] = sx ^ m_a; s[1] = sy ^ m_a;
     s[2] = sx ^ m_b; s[3] = sy ^ m_b;
     s[4] = sx ^ m_d; s[5] = sy ^ m_d;
-}
-ML_HD Board perm_net(const Board &b, uint32_t s1x, uint32_t s1y, uint32_t s2x, uint32_t s2y) {
-    const uint32_t t0 = perm_b32(b.r[2], b.r[0], s1x), t1 = perm_b32(b.r[2], b.r[0], s1y);
-    const uint32_t t2 = perm_b32(b.r[3], b.r[1], s1x), t3 = perm_b32(b.r[3], b.r[1], s1y);
-    Board o;
-    o.r[0] = perm_b32(t2, t0, s2x);
-    o.r[1] = perm_b32(t2, t0, s2y);
-    o.r[2] = perm_b32(t3, t1, s2x);
-    o.r[3] = perm_b32(t3, t1, s2y);
-    return o;
 }
 
 // ---- one line, pushed toward byte 0 (reference _push_row, game_numba.py:48-90) ---------------
